@@ -1,0 +1,226 @@
+/*
+ * vaegan_hip.h -- C ABI of the MI355X (gfx950) VAE-GAN training-path kernels.
+ *
+ * Drop-in boundary: the reference has no FFI layer -- its hot path is
+ * the nn.Module / Optimizer API used by vaegan_code.py:65-135, and every FLOP executes inside
+ * third-party ATen kernels.  This library replaces those ATen kernels.  Each entry point
+ * below names the reference call site(s) it serves.  Plain pointers + sizes only; all
+ * pointers are DEVICE pointers unless stated; every call is asynchronous on `stream`
+ * (a hipStream_t passed as void*) and performs no allocation and no host synchronisation,
+ * so call sequences can be captured into a hipGraph.
+ *
+ * Return value: 0 on success, a negative VG_E* code for rejected arguments (shape/alignment
+ * checks are done on the host BEFORE launch), or a positive hipError_t from the launch.
+ *
+ * Internal activation layout: NHWC ("pixel-major"), channel count padded to a multiple of
+ * 16 bytes (pad channels are zero).  dtype: VG_F32 (exact f32 MFMA, the parity path) or
+ * VG_BF16 (bf16 storage, f32 accumulate).  Parameters/gradients/optimizer state are f32 in
+ * the reference layouts (OIHW / [Cin][Cout][kh][kw]); `vg_pack_weights` produces the
+ * K-major operand copies the GEMM kernels read.
+ */
+#ifndef VAEGAN_HIP_H
+#define VAEGAN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VG_F32  0
+#define VG_BF16 1
+
+#define VG_EINVAL   (-1)   /* bad shape / size / flag                                  */
+#define VG_EALIGN   (-2)   /* pointer or channel count violates the 16-byte contract   */
+#define VG_ENOSUP   (-3)   /* unsupported configuration                                */
+
+#define VG_MAX_PHASE 4
+
+/* Activation codes for the fused BN/activation kernels. */
+#define VG_ACT_NONE    0
+#define VG_ACT_RELU    1   /* nn.ReLU(True)          gan_code.py:23-43            */
+#define VG_ACT_LRELU   2   /* nn.LeakyReLU(slope)    main_vae.py:25, gan_code.py:62-82 */
+
+int vg_abi_version(void);
+/* Which tile configuration the launcher would pick (for tests / bench reporting). */
+const char* vg_build_info(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Gather-GEMM: the one implicit-GEMM kernel behind
+ *   nn.Conv2d forward            (main_vae.py:23, gan_code.py:61-84)
+ *   nn.ConvTranspose2d forward   (gan_code.py:21-49)  -- 4-phase sub-pixel form for k4 s2 p1
+ *   their data gradients (autograd convolution_backward dgrad of vaegan_code.py:104,133)
+ *   nn.Linear forward / dgrad    (main_vae.py:47-48, 55-56) -- as a full-extent convolution
+ *
+ *   Y[b, gy*OSY+ooy[p], gx*OSX+oox[p], n] = bias[n] +
+ *        sum_{a<TH, c<TW, ci<IC} X[b, gy*SY + y0[p] + DY*a, gx*SX + x0[p] + DX*c, ci]
+ *                                 * W[p][n][(a*TW + c)*IC + ci]
+ *   for p < nphase, b < B, gy < GH, gx < GW, n < N; out-of-range input pixels read as 0,
+ *   out-of-range output pixels are skipped.  Optionally emits per-channel partial
+ *   (sum y, sum y*y) slabs for train-mode BatchNorm (nn.BatchNorm2d, main_vae.py:24).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct vg_gg_desc {
+    const void* X;        /* [B][IH][IW][IC]                                   */
+    const void* W;        /* packed [nphase][N][Kp] (Kp = padded TH*TW*IC)     */
+    void*       Y;        /* [B][OH][OW][OC]                                   */
+    const float* bias;    /* [N] or NULL                                       */
+    float*      stats;    /* partial slabs [nparts][2][N] or NULL              */
+    int32_t B, GH, GW;
+    int32_t IH, IW, IC;
+    int32_t SY, SX, DY, DX, TH, TW;
+    int32_t y0[VG_MAX_PHASE], x0[VG_MAX_PHASE];
+    int32_t N, Kp;
+    int32_t OH, OW, OC, OSY, OSX;
+    int32_t ooy[VG_MAX_PHASE], oox[VG_MAX_PHASE];
+    int32_t nphase;
+    int32_t stats_capacity;   /* number of [2][N] slabs `stats` can hold       */
+} vg_gg_desc;
+
+/* Number of stats slabs vg_gather_gemm will write for this descriptor (host-only query). */
+int vg_gather_gemm_nparts(const vg_gg_desc* d, int dtype);
+int vg_gather_gemm(const vg_gg_desc* d, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Weight gradient (autograd convolution_backward wgrad; Linear weight grad):
+ *   dW[np*s_np + cq*s_cq + (a*TW+c)*s_t] (+)= sum_{b,gy,gx}
+ *        P[b, gy, gx, np] * Q[b, gy*SY + y0 + DY*a, gx*SX + x0 + DX*c, cq]
+ * P is dense over the (GH,GW) grid, Q is gathered.  Conv2d: P=dY, Q=X; ConvTranspose2d:
+ * P=X, Q=dY.  Output f32 in the reference parameter layout.  Deterministic: split-M partial
+ * slabs in `ws` are reduced in fixed order.  accumulate!=0 adds into dW (autograd semantics
+ * of two D passes summed into one .grad, vaegan_code.py:99-104).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct vg_wg_desc {
+    const void* P;        /* [B][GH][GW][PC]                                   */
+    const void* Q;        /* [B][QH][QW][QC]                                   */
+    float*      dW;       /* f32, reference layout                             */
+    float*      ws;       /* workspace, ws_bytes                               */
+    int64_t     ws_bytes;
+    int32_t B, GH, GW, PC, NP;        /* NP real rows (<= PC)                   */
+    int32_t QH, QW, QC, NQ;           /* NQ real channels (<= QC)               */
+    int32_t SY, SX, DY, DX, TH, TW, y0, x0;
+    int32_t s_np, s_cq, s_t;          /* element strides into dW               */
+    int32_t accumulate;
+} vg_wg_desc;
+
+int64_t vg_wgrad_ws_bytes(const vg_wg_desc* d, int dtype);
+int vg_wgrad(const vg_wg_desc* d, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Operand packing: f32 parameter tensor (reference layout) -> K-major GEMM operand
+ *   dst[p][n][(a*TW+c)*IC + ci] = src[n*s_n + ci*s_c + kh(p,a)*KW + kw(p,c)]   (0 in padding)
+ *   kh(p,a) = kh0[p] + kh_step*a,  kw(p,c) = kw0[p] + kw_step*c
+ * tap_in_n != 0 selects the "taps are part of N" form used by the 1x1-input ConvTranspose2d
+ * (gan_code.py:21): dst[(kh*KW+kw)*CO + co][ci] = src[ci*s_c + co*s_n + kh*KW+kw].
+ * ---------------------------------------------------------------------------------------- */
+typedef struct vg_pack_desc {
+    const float* src;
+    void*        dst;
+    int32_t nphase, N, C, IC, TH, TW, Kp;
+    int32_t s_n, s_c, KW;
+    int32_t kh0[VG_MAX_PHASE], kw0[VG_MAX_PHASE], kh_step, kw_step;
+    int32_t tap_in_n, KHW;
+} vg_pack_desc;
+int vg_pack_weights(const vg_pack_desc* d, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * BatchNorm (train / eval) + activation, NHWC rows = B*H*W, C channels (C % 4 == 0).
+ * nn.BatchNorm2d semantics: biased batch variance for normalisation,
+ * unbiased for running_var, running = (1-m)*running + m*batch, eps inside the sqrt.
+ * ---------------------------------------------------------------------------------------- */
+/* Reduce the conv epilogue's partial slabs -> mean/invstd, scale/shift; update running stats. */
+int vg_bn_finalize(const float* stats, int nparts, int C, int64_t count,
+                   const float* gamma, const float* beta,
+                   float* running_mean, float* running_var, float momentum, float eps,
+                   float* mean, float* invstd, float* scale, float* shift, void* stream);
+/* Eval mode: scale/shift from running statistics. */
+int vg_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                      const float* running_var, float eps, int C,
+                      float* scale, float* shift, void* stream);
+/* y = act(scale[c]*x + shift[c]); scale/shift NULL -> pure activation. */
+int vg_bn_act_forward(const void* x, void* y, const float* scale, const float* shift,
+                      int64_t rows, int C, int act, float slope, int dtype, void* stream);
+/* Standalone per-channel statistics of an NHWC tensor (used when no conv epilogue produced them). */
+int vg_channel_stats(const void* x, int64_t rows, int C, float* stats, int stats_capacity,
+                     int* nparts_out, int dtype, void* stream);
+/* Backward pass 1: dz = dy_act * act'(z), z = scale*x+shift; partial sums of dz and dz*xhat. */
+int vg_bn_act_backward_reduce(const void* x, const void* dy, const float* scale, const float* shift,
+                              const float* mean, const float* invstd,
+                              int64_t rows, int C, int act, float slope,
+                              float* partial, int partial_capacity, int* nparts_out,
+                              int dtype, void* stream);
+/* Backward finalize: dgamma, dbeta (accumulate optional) and the two per-channel coefficients. */
+int vg_bn_backward_finalize(const float* partial, int nparts, int C, int64_t count,
+                            const float* gamma, const float* invstd,
+                            float* dgamma, float* dbeta, int accumulate,
+                            float* coef /* [3][C]: a, b, c */, void* stream);
+/* Backward pass 2: dx = a[c]*dz - b[c]*xhat - c[c]   (dz recomputed from dy, x). */
+int vg_bn_act_backward_apply(const void* x, const void* dy, void* dx,
+                             const float* scale, const float* shift,
+                             const float* mean, const float* invstd, const float* coef,
+                             int64_t rows, int C, int act, float slope, int dtype, void* stream);
+/* Activation-only backward (first Discriminator layer has no BN, gan_code.py:61-62). */
+int vg_act_backward(const void* x, const void* dy, void* dx, int64_t n, int act, float slope,
+                    int dtype, void* stream);
+/* dbias[c] (+)= sum over rows of dy[row][c]  (Conv2d bias grad, main_vae.py:23; Linear bias). */
+int vg_bias_grad(const void* dy, int64_t rows, int C, int NC, float* dbias, int accumulate,
+                 float* ws, int ws_capacity, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Layout / pointwise / losses
+ * ---------------------------------------------------------------------------------------- */
+/* NCHW f32 [B][C][H][W] -> NHWC dtype [B][H][W][CP] (pad channels zero); optional fused
+ * instance noise out = x + sigma*eps (vaegan_code.py:91-92), eps NCHW f32 or NULL. */
+int vg_nchw_to_nhwc(const float* x, const float* eps, float sigma, void* y,
+                    int B, int C, int H, int W, int CP, int dtype, void* stream);
+/* NHWC dtype -> NCHW f32, optional tanh (gan_code.py:50). */
+int vg_nhwc_to_nchw(const void* x, float* y, int B, int C, int H, int W, int CP,
+                    int apply_tanh, int dtype, void* stream);
+/* Gradient of the above: dy NCHW f32 -> dx NHWC dtype, optionally * (1 - t*t) with t = tanh output (NCHW f32). */
+int vg_nchw_grad_to_nhwc(const float* dy, const float* tanh_out, void* dx,
+                         int B, int C, int H, int W, int CP, int dtype, void* stream);
+/* Reparameterisation (vaegan_code.py:75-77): lv=clamp(logvar,-10,10); z=mu+exp(.5 lv)*eps.
+ * mulv: [B][MP] dtype, the fused fc_mu|fc_logvar output (main_vae.py:55-56): columns [0,L) = mu,
+ * [L,2L) = logvar.  eps: [B][L] f32.  z: [B][ZP] dtype (pad = 0).  lv_clamped: [B][L] f32. */
+int vg_reparam_forward(const void* mulv, const float* eps, void* z, float* lv_clamped,
+                       int B, int L, int MP, int ZP, int dtype, void* stream);
+/* KL (vaegan_code.py:114): out[0] = -0.5*sum(1+lv-mu^2-exp(lv)) / divisor. */
+int vg_kl_forward(const void* mulv, const float* lv_clamped, int B, int L, int MP, float divisor,
+                  float* out, int dtype, void* stream);
+/* d(mu|logvar) [B][MP] dtype from dz [B][ZP] dtype and kl_scale = alpha_kl*min(1,epoch/50)/B
+ * (vaegan_code.py:114,117); the clamp passes gradient on [-10,10] only. */
+int vg_reparam_kl_backward(const void* mulv, const float* lv_clamped, const float* eps,
+                           const void* dz, float kl_scale, void* dmulv,
+                           int B, int L, int MP, int ZP, int dtype, void* stream);
+/* Discriminator head (gan_code.py:84-85,89): p[b] = sigmoid(dot(x[b,:], w)), x NHWC-flattened. */
+int vg_dot_sigmoid_forward(const void* x, const void* w, float* p, int B, int K, int dtype, void* stream);
+/* dlogit[b] = dp[b]*p*(1-p); dx[b,k] = dlogit[b]*w[k]  (dx NULL -> skipped). */
+int vg_dot_sigmoid_backward(const float* p, const float* dp, const void* w, void* dx, float* dlogit,
+                            int B, int K, int dtype, void* stream);
+/* dw[k] (+)= sum_b dlogit[b]*x[b,k] -> f32 in reference layout via perm (k_nhwc -> offset). */
+int vg_dot_wgrad(const void* x, const float* dlogit, float* dw, int B, int K, int C, int HW,
+                 int accumulate, int dtype, void* stream);
+/* nn.BCELoss (vaegan_code.py:46): mean_b -(t*max(log p,-100)+(1-t)*max(log(1-p),-100));
+ * loss[0] (+)= value when accumulate; dp[b] = gscale*(p-t)/max(p*(1-p),1e-12)/B (dp NULL ok). */
+int vg_bce_forward_backward(const float* p, float target, int B, float gscale,
+                            float* loss, int accumulate, float* dp, void* stream);
+/* nn.MSELoss(mean) (vaegan_code.py:47) on NCHW f32 tensors; d_a = gscale*2*(a-b)/n (NULL ok). */
+int vg_mse_forward_backward(const float* a, const float* b, int64_t n, float gscale,
+                            float* loss, float* d_a, float* ws, int ws_capacity, void* stream);
+/* out = a + alpha*b (f32, n elements); used for gradient joins on NCHW images. */
+int vg_axpy(const float* a, const float* b, float alpha, float* out, int64_t n, void* stream);
+/* PSNR/SSIM support for the denoise path lives in vg_image_metrics. */
+
+/* ------------------------------------------------------------------------------------------
+ * Adam (torch.optim.Adam defaults as used at vaegan_code.py:42-44; arithmetic of torch 2.10
+ * _single_tensor_adam): one launch over a flat f32 buffer.
+ * state[0] = step count as float (incremented on device first), so the call is graph-replayable.
+ * grad_scale multiplies g before use (1/world_size after an all-reduce SUM).
+ * ---------------------------------------------------------------------------------------- */
+int vg_adam_step(float* p, const float* g, float* m, float* v, int64_t n,
+                 double lr, double beta1, double beta2, double eps, float grad_scale,
+                 float* state /* [4] device */, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VAEGAN_HIP_H */

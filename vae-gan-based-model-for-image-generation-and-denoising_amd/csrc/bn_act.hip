@@ -1,0 +1,362 @@
+// BatchNorm2d (train/eval) + ReLU/LeakyReLU forward and backward on NHWC tensors.
+// Replaces the ATen batch_norm / leaky_relu / relu kernels reached through nn.BatchNorm2d,
+// nn.LeakyReLU and nn.ReLU at main_vae.py:24-25 and gan_code.py:22-82 (+ their backward).
+//
+// All tensors are [rows = B*H*W][C] with C contiguous, so a per-channel reduction is a column
+// sum: a workgroup owns a contiguous block of rows, each thread a fixed 4-channel column
+// (16-byte loads, fully coalesced), partial sums go wave -> LDS -> one slab row per
+// workgroup, and a one-thread-per-channel finalize kernel adds the slab rows in fixed order
+// in double precision.  HBM-bound: ideal traffic is one read (+ one write) of the tensor.
+#include "common.hpp"
+
+namespace {
+
+struct RedPlan { int nparts, rows_per_part, ncolblk; };
+
+inline RedPlan plan_reduce(int64_t rows, int C) {
+    const int cols = C / 4;
+    const int ncol = cols < 256 ? cols : 256;
+    const int rpp = 256 / ncol;
+    const int64_t passes = (rows + rpp - 1) / rpp;
+    int64_t np = passes / 8;
+    if (np < 1) np = 1;
+    if (np > 1024) np = 1024;
+    int64_t rows_per_part = ((passes + np - 1) / np) * rpp;
+    RedPlan p;
+    p.nparts = (int)((rows + rows_per_part - 1) / rows_per_part);
+    p.rows_per_part = (int)rows_per_part;
+    p.ncolblk = (cols + 255) / 256;
+    return p;
+}
+
+// MODE 0: (sum x, sum x*x).  MODE 1: (sum dz, sum dz*xhat) with dz = dy*act'(scale*x+shift).
+template <int DT, int MODE>
+__global__ __launch_bounds__(256) void col_reduce_kernel(const void* __restrict__ x, const void* __restrict__ dy,
+                                                         const float* __restrict__ scale,
+                                                         const float* __restrict__ shift,
+                                                         const float* __restrict__ mean,
+                                                         const float* __restrict__ invstd, int64_t rows, int C,
+                                                         int act, float slope, float* __restrict__ partial,
+                                                         int rows_per_part) {
+    __shared__ float4 red[2][256];
+    const int cols = C >> 2;
+    const int cb = blockIdx.y * 256;
+    const int ncol = min(256, cols - cb);
+    const int rpp = 256 / ncol;
+    const int tid = threadIdx.x;
+    const int tr = tid / ncol, tc = tid - tr * ncol;
+    const bool active = tr < rpp;
+    const int c4 = (cb + tc) * 4;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_part;
+    const int64_t r1 = min(rows, r0 + (int64_t)rows_per_part);
+    float4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    if (active) {
+        float4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f}, mu = sh, is = sc;
+        if (MODE == 1) {
+            if (scale) { sc = *reinterpret_cast<const float4*>(scale + c4); sh = *reinterpret_cast<const float4*>(shift + c4); }
+            mu = *reinterpret_cast<const float4*>(mean + c4);
+            is = *reinterpret_cast<const float4*>(invstd + c4);
+        }
+        for (int64_t r = r0 + tr; r < r1; r += rpp) {
+            const float4 v = load4<DT>(x, r * C + c4);
+            if (MODE == 0) {
+                s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+                s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
+            } else {
+                const float4 g = load4<DT>(dy, r * C + c4);
+                const float dz0 = act_bwd(sc.x * v.x + sh.x, g.x, act, slope);
+                const float dz1 = act_bwd(sc.y * v.y + sh.y, g.y, act, slope);
+                const float dz2 = act_bwd(sc.z * v.z + sh.z, g.z, act, slope);
+                const float dz3 = act_bwd(sc.w * v.w + sh.w, g.w, act, slope);
+                s1.x += dz0; s1.y += dz1; s1.z += dz2; s1.w += dz3;
+                s2.x += dz0 * ((v.x - mu.x) * is.x); s2.y += dz1 * ((v.y - mu.y) * is.y);
+                s2.z += dz2 * ((v.z - mu.z) * is.z); s2.w += dz3 * ((v.w - mu.w) * is.w);
+            }
+        }
+    }
+    red[0][tid] = s1;
+    red[1][tid] = s2;
+    __syncthreads();
+    if (tid < ncol) {
+        float4 a = red[0][tid], b = red[1][tid];
+        for (int k = 1; k < rpp; ++k) {
+            const float4 u = red[0][k * ncol + tid], w = red[1][k * ncol + tid];
+            a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+            b.x += w.x; b.y += w.y; b.z += w.z; b.w += w.w;
+        }
+        const int64_t part = blockIdx.x;
+        *reinterpret_cast<float4*>(partial + (part * 2 + 0) * C + c4) = a;
+        *reinterpret_cast<float4*>(partial + (part * 2 + 1) * C + c4) = b;
+    }
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ stats, int nparts, int C, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
+                                   float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale,
+                                   float* __restrict__ shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int p = 0; p < nparts; ++p) {
+        s1 += (double)stats[((int64_t)p * 2 + 0) * C + c];
+        s2 += (double)stats[((int64_t)p * 2 + 1) * C + c];
+    }
+    const double mu = s1 / count;
+    double var = s2 / count - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    const float muf = (float)mu;
+    mean[c] = muf;
+    invstd[c] = is;
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float sc = g * is;
+    scale[c] = sc;
+    shift[c] = b - muf * sc;
+    if (rmean) {
+        const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * muf;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+    }
+}
+
+__global__ void bn_eval_kernel(const float* gamma, const float* beta, const float* rmean, const float* rvar,
+                               float eps, int C, float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float is = 1.f / sqrtf(rvar[c] + eps);
+    const float sc = (gamma ? gamma[c] : 1.f) * is;
+    scale[c] = sc;
+    shift[c] = (beta ? beta[c] : 0.f) - rmean[c] * sc;
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const void* __restrict__ x, void* __restrict__ y,
+                                                         const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, int64_t nvec, int cols,
+                                                         int act, float slope) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % cols) * 4;
+        float4 v = load4<DT>(x, i * 4);
+        if (scale) {
+            const float4 sc = *reinterpret_cast<const float4*>(scale + c4);
+            const float4 sh = *reinterpret_cast<const float4*>(shift + c4);
+            v.x = sc.x * v.x + sh.x; v.y = sc.y * v.y + sh.y; v.z = sc.z * v.z + sh.z; v.w = sc.w * v.w + sh.w;
+        }
+        v.x = act_fwd(v.x, act, slope); v.y = act_fwd(v.y, act, slope);
+        v.z = act_fwd(v.z, act, slope); v.w = act_fwd(v.w, act, slope);
+        store4<DT>(y, i * 4, v);
+    }
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nparts, int C, double count,
+                                       const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
+                                       float* __restrict__ coef) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int p = 0; p < nparts; ++p) {
+        s1 += (double)partial[((int64_t)p * 2 + 0) * C + c];
+        s2 += (double)partial[((int64_t)p * 2 + 1) * C + c];
+    }
+    const float fs1 = (float)s1, fs2 = (float)s2;
+    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + fs2 : fs2;
+    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + fs1 : fs1;
+    const float a = (gamma ? gamma[c] : 1.f) * invstd[c];
+    coef[c] = a;
+    coef[C + c] = (float)((double)a * s2 / count);
+    coef[2 * C + c] = (float)((double)a * s1 / count);
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const void* __restrict__ x, const void* __restrict__ dy,
+                                                               void* __restrict__ dx,
+                                                               const float* __restrict__ scale,
+                                                               const float* __restrict__ shift,
+                                                               const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd,
+                                                               const float* __restrict__ coef, int64_t nvec, int cols,
+                                                               int C, int act, float slope) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % cols) * 4;
+        const float4 v = load4<DT>(x, i * 4);
+        const float4 g = load4<DT>(dy, i * 4);
+        const float4 sc = *reinterpret_cast<const float4*>(scale + c4);
+        const float4 sh = *reinterpret_cast<const float4*>(shift + c4);
+        const float4 mu = *reinterpret_cast<const float4*>(mean + c4);
+        const float4 is = *reinterpret_cast<const float4*>(invstd + c4);
+        const float4 ca = *reinterpret_cast<const float4*>(coef + c4);
+        const float4 cbv = *reinterpret_cast<const float4*>(coef + C + c4);
+        const float4 cc = *reinterpret_cast<const float4*>(coef + 2 * C + c4);
+        float4 o;
+        o.x = ca.x * act_bwd(sc.x * v.x + sh.x, g.x, act, slope) - cbv.x * ((v.x - mu.x) * is.x) - cc.x;
+        o.y = ca.y * act_bwd(sc.y * v.y + sh.y, g.y, act, slope) - cbv.y * ((v.y - mu.y) * is.y) - cc.y;
+        o.z = ca.z * act_bwd(sc.z * v.z + sh.z, g.z, act, slope) - cbv.z * ((v.z - mu.z) * is.z) - cc.z;
+        o.w = ca.w * act_bwd(sc.w * v.w + sh.w, g.w, act, slope) - cbv.w * ((v.w - mu.w) * is.w) - cc.w;
+        store4<DT>(dx, i * 4, o);
+    }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const void* __restrict__ x, const void* __restrict__ dy,
+                                                      void* __restrict__ dx, int64_t nvec, int act, float slope) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = load4<DT>(x, i * 4);
+        const float4 g = load4<DT>(dy, i * 4);
+        float4 o;
+        o.x = act_bwd(v.x, g.x, act, slope); o.y = act_bwd(v.y, g.y, act, slope);
+        o.z = act_bwd(v.z, g.z, act, slope); o.w = act_bwd(v.w, g.w, act, slope);
+        store4<DT>(dx, i * 4, o);
+    }
+}
+
+__global__ void bias_finalize_kernel(const float* __restrict__ partial, int nparts, int C, int NC,
+                                     float* __restrict__ dbias, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= NC) return;
+    double s = 0.0;
+    for (int p = 0; p < nparts; ++p) s += (double)partial[((int64_t)p * 2) * C + c];
+    dbias[c] = accumulate ? dbias[c] + (float)s : (float)s;
+}
+
+inline int ew_blocks(int64_t nvec) {
+    int64_t b = (nvec + 255) / 256;
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+inline int check_rows_c(const void* x, int64_t rows, int C, int dtype) {
+    VG_CHECK_ARG(x != nullptr && rows > 0 && C > 0, VG_EINVAL);
+    VG_CHECK_ARG(dtype == VG_F32 || dtype == VG_BF16, VG_ENOSUP);
+    VG_CHECK_ARG(C % 4 == 0, VG_EALIGN);
+    VG_CHECK_ARG((reinterpret_cast<uintptr_t>(x) & 7u) == 0, VG_EALIGN);
+    return 0;
+}
+
+template <int MODE>
+int launch_reduce(const void* x, const void* dy, const float* scale, const float* shift, const float* mean,
+                  const float* invstd, int64_t rows, int C, int act, float slope, float* partial, int capacity,
+                  int* nparts_out, int dtype, hipStream_t s) {
+    RedPlan p = plan_reduce(rows, C);
+    if (nparts_out) *nparts_out = p.nparts;
+    VG_CHECK_ARG(partial != nullptr && capacity >= p.nparts, VG_EINVAL);
+    dim3 grid(p.nparts, p.ncolblk);
+    if (dtype == VG_F32)
+        hipLaunchKernelGGL((col_reduce_kernel<VG_F32, MODE>), grid, dim3(256), 0, s, x, dy, scale, shift, mean, invstd,
+                           rows, C, act, slope, partial, p.rows_per_part);
+    else
+        hipLaunchKernelGGL((col_reduce_kernel<VG_BF16, MODE>), grid, dim3(256), 0, s, x, dy, scale, shift, mean, invstd,
+                           rows, C, act, slope, partial, p.rows_per_part);
+    return VG_LAUNCH_RC();
+}
+
+}  // namespace
+
+extern "C" int vg_bn_finalize(const float* stats, int nparts, int C, int64_t count, const float* gamma,
+                              const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                              float* mean, float* invstd, float* scale, float* shift, void* stream) {
+    VG_CHECK_ARG(stats && nparts > 0 && C > 0 && count > 0 && mean && invstd && scale && shift, VG_EINVAL);
+    VG_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), VG_EINVAL);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, vg_stream(stream), stats, nparts, C,
+                       (double)count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale,
+                       shift);
+    return VG_LAUNCH_RC();
+}
+
+extern "C" int vg_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                                 const float* running_var, float eps, int C, float* scale, float* shift,
+                                 void* stream) {
+    VG_CHECK_ARG(running_mean && running_var && scale && shift && C > 0, VG_EINVAL);
+    hipLaunchKernelGGL(bn_eval_kernel, dim3((C + 63) / 64), dim3(64), 0, vg_stream(stream), gamma, beta, running_mean,
+                       running_var, eps, C, scale, shift);
+    return VG_LAUNCH_RC();
+}
+
+extern "C" int vg_bn_act_forward(const void* x, void* y, const float* scale, const float* shift, int64_t rows, int C,
+                                 int act, float slope, int dtype, void* stream) {
+    int rc = check_rows_c(x, rows, C, dtype);
+    if (rc) return rc;
+    VG_CHECK_ARG(y != nullptr && (scale == nullptr) == (shift == nullptr), VG_EINVAL);
+    const int64_t nvec = rows * C / 4;
+    if (dtype == VG_F32)
+        hipLaunchKernelGGL(bn_act_fwd_kernel<VG_F32>, dim3(ew_blocks(nvec)), dim3(256), 0, vg_stream(stream), x, y,
+                           scale, shift, nvec, C / 4, act, slope);
+    else
+        hipLaunchKernelGGL(bn_act_fwd_kernel<VG_BF16>, dim3(ew_blocks(nvec)), dim3(256), 0, vg_stream(stream), x, y,
+                           scale, shift, nvec, C / 4, act, slope);
+    return VG_LAUNCH_RC();
+}
+
+extern "C" int vg_channel_stats(const void* x, int64_t rows, int C, float* stats, int stats_capacity,
+                                int* nparts_out, int dtype, void* stream) {
+    int rc = check_rows_c(x, rows, C, dtype);
+    if (rc) return rc;
+    return launch_reduce<0>(x, nullptr, nullptr, nullptr, nullptr, nullptr, rows, C, 0, 0.f, stats, stats_capacity,
+                            nparts_out, dtype, vg_stream(stream));
+}
+
+extern "C" int vg_bn_act_backward_reduce(const void* x, const void* dy, const float* scale, const float* shift,
+                                         const float* mean, const float* invstd, int64_t rows, int C, int act,
+                                         float slope, float* partial, int partial_capacity, int* nparts_out,
+                                         int dtype, void* stream) {
+    int rc = check_rows_c(x, rows, C, dtype);
+    if (rc) return rc;
+    VG_CHECK_ARG(dy && scale && shift && mean && invstd, VG_EINVAL);
+    return launch_reduce<1>(x, dy, scale, shift, mean, invstd, rows, C, act, slope, partial, partial_capacity,
+                            nparts_out, dtype, vg_stream(stream));
+}
+
+extern "C" int vg_bn_backward_finalize(const float* partial, int nparts, int C, int64_t count, const float* gamma,
+                                       const float* invstd, float* dgamma, float* dbeta, int accumulate, float* coef,
+                                       void* stream) {
+    VG_CHECK_ARG(partial && nparts > 0 && C > 0 && count > 0 && invstd && coef, VG_EINVAL);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, vg_stream(stream), partial, nparts, C,
+                       (double)count, gamma, invstd, dgamma, dbeta, accumulate, coef);
+    return VG_LAUNCH_RC();
+}
+
+extern "C" int vg_bn_act_backward_apply(const void* x, const void* dy, void* dx, const float* scale,
+                                        const float* shift, const float* mean, const float* invstd, const float* coef,
+                                        int64_t rows, int C, int act, float slope, int dtype, void* stream) {
+    int rc = check_rows_c(x, rows, C, dtype);
+    if (rc) return rc;
+    VG_CHECK_ARG(dy && dx && scale && shift && mean && invstd && coef, VG_EINVAL);
+    const int64_t nvec = rows * C / 4;
+    if (dtype == VG_F32)
+        hipLaunchKernelGGL(bn_act_bwd_apply_kernel<VG_F32>, dim3(ew_blocks(nvec)), dim3(256), 0, vg_stream(stream), x,
+                           dy, dx, scale, shift, mean, invstd, coef, nvec, C / 4, C, act, slope);
+    else
+        hipLaunchKernelGGL(bn_act_bwd_apply_kernel<VG_BF16>, dim3(ew_blocks(nvec)), dim3(256), 0, vg_stream(stream), x,
+                           dy, dx, scale, shift, mean, invstd, coef, nvec, C / 4, C, act, slope);
+    return VG_LAUNCH_RC();
+}
+
+extern "C" int vg_act_backward(const void* x, const void* dy, void* dx, int64_t n, int act, float slope, int dtype,
+                               void* stream) {
+    VG_CHECK_ARG(x && dy && dx && n > 0 && n % 4 == 0, VG_EINVAL);
+    VG_CHECK_ARG(dtype == VG_F32 || dtype == VG_BF16, VG_ENOSUP);
+    const int64_t nvec = n / 4;
+    if (dtype == VG_F32)
+        hipLaunchKernelGGL(act_bwd_kernel<VG_F32>, dim3(ew_blocks(nvec)), dim3(256), 0, vg_stream(stream), x, dy, dx,
+                           nvec, act, slope);
+    else
+        hipLaunchKernelGGL(act_bwd_kernel<VG_BF16>, dim3(ew_blocks(nvec)), dim3(256), 0, vg_stream(stream), x, dy, dx,
+                           nvec, act, slope);
+    return VG_LAUNCH_RC();
+}
+
+extern "C" int vg_bias_grad(const void* dy, int64_t rows, int C, int NC, float* dbias, int accumulate, float* ws,
+                            int ws_capacity, int dtype, void* stream) {
+    int rc = check_rows_c(dy, rows, C, dtype);
+    if (rc) return rc;
+    VG_CHECK_ARG(dbias && ws && NC > 0 && NC <= C, VG_EINVAL);
+    int nparts = 0;
+    rc = launch_reduce<0>(dy, nullptr, nullptr, nullptr, nullptr, nullptr, rows, C, 0, 0.f, ws, ws_capacity, &nparts,
+                          dtype, vg_stream(stream));
+    if (rc) return rc;
+    hipLaunchKernelGGL(bias_finalize_kernel, dim3((NC + 63) / 64), dim3(64), 0, vg_stream(stream), ws, nparts, C, NC,
+                       dbias, accumulate);
+    return VG_LAUNCH_RC();
+}

@@ -1,0 +1,90 @@
+// Shared device/host helpers for the gfx950 VAE-GAN kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "vaegan_hip.h"
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+#define VG_CHECK_ARG(cond, code) do { if (!(cond)) return (code); } while (0)
+#define VG_LAUNCH_RC() ((int)hipGetLastError())
+
+static inline hipStream_t vg_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline bool vg_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---- element traits -------------------------------------------------------------------------
+template <int DT> struct ElemT;
+template <> struct ElemT<VG_F32> {
+    typedef float type;
+    static constexpr int size = 4;
+    static constexpr int per16 = 4;
+    __device__ static __forceinline__ float to_f32(float v) { return v; }
+    __device__ static __forceinline__ float from_f32(float v) { return v; }
+};
+template <> struct ElemT<VG_BF16> {
+    typedef uint16_t type;
+    static constexpr int size = 2;
+    static constexpr int per16 = 8;
+    __device__ static __forceinline__ float to_f32(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+    // plain cast keeps NaN a NaN (v_cvt_pk_bf16_f32), MI355X_MICROARCH.md "Correctness boundaries"
+    __device__ static __forceinline__ uint16_t from_f32(float v) {
+        __bf16 b = (__bf16)v;
+        return __builtin_bit_cast(uint16_t, b);
+    }
+};
+
+// load / store a run of 4 consecutive elements as floats (16 B for f32, 8 B for bf16)
+template <int DT> __device__ __forceinline__ float4 load4(const void* base, int64_t idx);
+template <> __device__ __forceinline__ float4 load4<VG_F32>(const void* base, int64_t idx) {
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + idx);
+}
+template <> __device__ __forceinline__ float4 load4<VG_BF16>(const void* base, int64_t idx) {
+    uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + idx);
+    float4 o;
+    o.x = __uint_as_float(r.x << 16);
+    o.y = __uint_as_float(r.x & 0xffff0000u);
+    o.z = __uint_as_float(r.y << 16);
+    o.w = __uint_as_float(r.y & 0xffff0000u);
+    return o;
+}
+template <int DT> __device__ __forceinline__ void store4(void* base, int64_t idx, float4 v);
+template <> __device__ __forceinline__ void store4<VG_F32>(void* base, int64_t idx, float4 v) {
+    *reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + idx) = v;
+}
+template <> __device__ __forceinline__ void store4<VG_BF16>(void* base, int64_t idx, float4 v) {
+    uint2 r;
+    r.x = (uint32_t)ElemT<VG_BF16>::from_f32(v.x) | ((uint32_t)ElemT<VG_BF16>::from_f32(v.y) << 16);
+    r.y = (uint32_t)ElemT<VG_BF16>::from_f32(v.z) | ((uint32_t)ElemT<VG_BF16>::from_f32(v.w) << 16);
+    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(base) + idx) = r;
+}
+template <int DT> __device__ __forceinline__ float load1(const void* base, int64_t idx) {
+    return ElemT<DT>::to_f32(reinterpret_cast<const typename ElemT<DT>::type*>(base)[idx]);
+}
+template <int DT> __device__ __forceinline__ void store1(void* base, int64_t idx, float v) {
+    reinterpret_cast<typename ElemT<DT>::type*>(base)[idx] = ElemT<DT>::from_f32(v);
+}
+
+__device__ __forceinline__ float act_fwd(float z, int act, float slope) {
+    if (act == VG_ACT_RELU) return z > 0.f ? z : 0.f;
+    if (act == VG_ACT_LRELU) return z > 0.f ? z : z * slope;
+    return z;
+}
+// derivative selected on the pre-activation z (torch: relu' = z>0, leaky' = z>0 ? 1 : slope)
+__device__ __forceinline__ float act_bwd(float z, float g, int act, float slope) {
+    if (act == VG_ACT_RELU) return z > 0.f ? g : 0.f;
+    if (act == VG_ACT_LRELU) return z > 0.f ? g : g * slope;
+    return g;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}

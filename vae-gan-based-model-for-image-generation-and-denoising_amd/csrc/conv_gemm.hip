@@ -1,0 +1,318 @@
+// Gather-GEMM: implicit-GEMM convolution / transposed convolution / linear on MFMA (gfx950).
+//
+// Replaces the ATen kernels behind nn.Conv2d (main_vae.py:23, gan_code.py:61-84),
+// nn.ConvTranspose2d (gan_code.py:21-49), nn.Linear (main_vae.py:47-48) and their data
+// gradients.  Semantics: vg_gg_desc in include/vaegan_hip.h.
+//
+// Structure (cdna_hip_programming.md section 5, register-staged 2-buffer loop):
+//   * one workgroup = 4 waves = BM x BN output tile; wave tile = (BM/WM) x (BN/WN) made of
+//     16x16 MFMA tiles (v_mfma_f32_16x16x4_f32 for f32 -- an exact f32 FMA chain --,
+//     v_mfma_f32_16x16x32_bf16 for bf16 storage with f32 accumulate);
+//   * K is walked in 64-byte "chunks" per row (16 f32 / 32 bf16): each thread gathers one
+//     16-byte unit per row-pass straight from the NHWC activation (a unit never straddles a
+//     filter tap because IC*esize % 16 == 0) and zero-fills out-of-image taps, so no
+//     zero-inserted or padded MACs are read from HBM;
+//   * LDS image: [row][64 B] with the 16-byte slot XOR-swizzled by row (slot ^= (-(row>>2))&3)
+//     -> conflict-free ds_read_b128 fragment reads and conflict-free ds_write_b128 staging;
+//   * loads for chunk k+1 are issued before the MFMAs of chunk k and written to the other LDS
+//     buffer after them (T14 issue-early / write-late), one barrier per chunk;
+//   * epilogue: + bias, scatter to the NHWC output (phase/sub-pixel offsets), and optional
+//     per-channel (sum, sum of squares) partials for train-mode BatchNorm, reduced
+//     wave -> LDS -> one slab row per workgroup (deterministic, no atomics).
+#include "common.hpp"
+
+namespace {
+
+template <int DT, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void gg_kernel(const vg_gg_desc d) {
+    typedef ElemT<DT> E;
+    constexpr int ESZ = E::size;
+    constexpr int TM = BM / WM / 16;
+    constexpr int TN = BN / WN / 16;
+    constexpr int AP = BM / 64;                    // A row passes per chunk
+    constexpr int BP = (BN + 63) / 64;             // B row passes per chunk
+    constexpr int STAGE = (BM + BN) * 64;          // bytes per LDS buffer
+    static_assert(WM * WN == 4, "4 waves");
+    static_assert(BM % 64 == 0, "BM multiple of 64");
+
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int phase = blockIdx.z;
+    const int m0 = blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int M = d.B * d.GH * d.GW;
+    const int GHW = d.GH * d.GW;
+
+    const int lrow = tid >> 2;                     // 0..63
+    const int q = tid & 3;                         // 16-byte unit within the chunk
+    const int upt = (d.IC * ESZ) >> 4;             // 16-byte units per tap
+    const int k16 = d.TH * d.TW * upt;             // valid units along K
+    const int nchunks = (d.Kp * ESZ) >> 6;
+
+    // ---- per-thread gather bases for its A rows ----
+    int a_img[AP], a_iy[AP], a_ix[AP];
+    bool a_ok[AP];
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+        const int m = m0 + lrow + 64 * i;
+        a_ok[i] = m < M;
+        const int mm = a_ok[i] ? m : 0;
+        const int b = mm / GHW;
+        const int r = mm - b * GHW;
+        const int gy = r / d.GW;
+        const int gx = r - gy * d.GW;
+        a_img[i] = b * d.IH * d.IW;
+        a_iy[i] = gy * d.SY + d.y0[phase];
+        a_ix[i] = gx * d.SX + d.x0[phase];
+    }
+    const unsigned char* Xb = reinterpret_cast<const unsigned char*>(d.X);
+    const unsigned char* Wb = reinterpret_cast<const unsigned char*>(d.W);
+    const int64_t pix_bytes = (int64_t)d.IC * ESZ;
+    const int64_t wrow_bytes = (int64_t)d.Kp * ESZ;
+    int64_t b_off[BP];
+    bool b_ok[BP];
+#pragma unroll
+    for (int j = 0; j < BP; ++j) {
+        const int n = n0 + lrow + 64 * j;
+        b_ok[j] = (lrow + 64 * j < BN) && (n < d.N);
+        b_off[j] = ((int64_t)phase * d.N + (b_ok[j] ? n : 0)) * wrow_bytes;
+    }
+
+    u32x4 ra[AP], rb[BP];
+    auto load_chunk = [&](int kc) {
+        const int u = kc * 4 + q;
+        const bool uok = u < k16;
+        const int t = u / upt;
+        const int cu = u - t * upt;
+        const int ta = t / d.TW;
+        const int tb = t - ta * d.TW;
+        const int dy = d.DY * ta, dx = d.DX * tb;
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
+            const bool ok = a_ok[i] && uok && (unsigned)iy < (unsigned)d.IH && (unsigned)ix < (unsigned)d.IW;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (ok) v = *reinterpret_cast<const u32x4*>(Xb + (int64_t)(a_img[i] + iy * d.IW + ix) * pix_bytes + cu * 16);
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < BP; ++j) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (b_ok[j]) v = *reinterpret_cast<const u32x4*>(Wb + b_off[j] + (int64_t)u * 16);
+            rb[j] = v;
+        }
+    };
+    auto store_chunk = [&](int buf) {
+        unsigned char* sa = smem + buf * STAGE;
+        unsigned char* sb = sa + BM * 64;
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            const int r = lrow + 64 * i;
+            *reinterpret_cast<u32x4*>(sa + r * 64 + ((q ^ ((-(r >> 2)) & 3)) << 4)) = ra[i];
+        }
+#pragma unroll
+        for (int j = 0; j < BP; ++j) {
+            const int r = lrow + 64 * j;
+            if (r < BN) *reinterpret_cast<u32x4*>(sb + r * 64 + ((q ^ ((-(r >> 2)) & 3)) << 4)) = rb[j];
+        }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15;       // row within the 16x16 operand tile
+    const int fg = lane >> 4;       // 16-byte unit (k group)
+
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+
+    for (int kc = 0; kc < nchunks; ++kc) {
+        const int buf = kc & 1;
+        if (kc + 1 < nchunks) load_chunk(kc + 1);
+        const unsigned char* sa = smem + buf * STAGE;
+        const unsigned char* sb = sa + BM * 64;
+        u32x4 fa[TM], fb[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int r = wm * (BM / WM) + i * 16 + fr;
+            fa[i] = *reinterpret_cast<const u32x4*>(sa + r * 64 + ((fg ^ ((-(r >> 2)) & 3)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int r = wn * (BN / WN) + j * 16 + fr;
+            fb[j] = *reinterpret_cast<const u32x4*>(sb + r * 64 + ((fg ^ ((-(r >> 2)) & 3)) << 4));
+        }
+        if constexpr (DT == VG_F32) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                            __uint_as_float(fa[i][kk]), __uint_as_float(fb[j][kk]), acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
+        }
+        if (kc + 1 < nchunks) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---------------- epilogue ----------------
+    const bool flat = (d.nphase == 1 && d.OSY == 1 && d.OSX == 1 && d.GH == d.OH && d.GW == d.OW);
+    const bool want_stats = d.stats != nullptr;
+    float s1[TN], s2[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    float biasv[TN];
+    int ncol[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        ncol[j] = n0 + wn * (BN / WN) + j * 16 + fr;
+        biasv[j] = (d.bias != nullptr && ncol[j] < d.N) ? d.bias[ncol[j]] : 0.f;
+    }
+    unsigned char* Yb = reinterpret_cast<unsigned char*>(d.Y);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wm * (BM / WM) + i * 16 + fg * 4 + r;
+            bool ok = m < M;
+            int64_t opix = m;
+            if (!flat && ok) {
+                const int b = m / GHW;
+                const int rem = m - b * GHW;
+                const int gy = rem / d.GW;
+                const int gx = rem - gy * d.GW;
+                const int oy = gy * d.OSY + d.ooy[phase];
+                const int ox = gx * d.OSX + d.oox[phase];
+                ok = (oy < d.OH) && (ox < d.OW);
+                opix = ((int64_t)b * d.OH + oy) * d.OW + ox;
+            }
+            if (!ok) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = ncol[j];
+                if (n < d.OC) {
+                    float v = 0.f;
+                    if (n < d.N) {
+                        v = acc[i][j][r] + biasv[j];
+                        s1[j] += v;
+                        s2[j] += v * v;
+                    }
+                    store1<DT>(Yb, opix * d.OC + n, v);
+                }
+            }
+        }
+    }
+    if (want_stats) {
+        float* red = reinterpret_cast<float*>(smem);            // [WM][BN][2]
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float a = s1[j], b = s2[j];
+            a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
+            b += __shfl_xor(b, 16); b += __shfl_xor(b, 32);
+            if (fg == 0) {
+                const int c = wn * (BN / WN) + j * 16 + fr;
+                red[(wm * BN + c) * 2 + 0] = a;
+                red[(wm * BN + c) * 2 + 1] = b;
+            }
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < d.N) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) { a += red[(w * BN + tid) * 2]; b += red[(w * BN + tid) * 2 + 1]; }
+            const int64_t part = (int64_t)phase * gridDim.x + blockIdx.x;
+            d.stats[(part * 2 + 0) * d.N + n0 + tid] = a;
+            d.stats[(part * 2 + 1) * d.N + n0 + tid] = b;
+        }
+    }
+}
+
+struct TileCfg { int bm, bn; };
+
+inline int tiles_of(int M, int N, int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); }
+
+// Pick the output tile: small-N layers get tall-skinny tiles (they are HBM-bound); otherwise the
+// largest tile that still fills the 256 CUs with >= ~2 workgroups each.
+inline TileCfg pick_tile(const vg_gg_desc* d) {
+    const int M = d->B * d->GH * d->GW;
+    const int N = d->N;
+    const int ph = d->nphase;
+    if (N <= 16) return {256, 16};
+    if (N <= 32) return {128, 32};
+    if (N > 64 && tiles_of(M, N, 128, 128) * ph >= 512) return {128, 128};
+    if (tiles_of(M, N, 128, 64) * ph >= 512) return {128, 64};
+    return {64, 64};
+}
+
+inline int validate(const vg_gg_desc* d, int dtype) {
+    VG_CHECK_ARG(d != nullptr, VG_EINVAL);
+    VG_CHECK_ARG(dtype == VG_F32 || dtype == VG_BF16, VG_ENOSUP);
+    const int esz = dtype == VG_F32 ? 4 : 2;
+    VG_CHECK_ARG(d->X && d->W && d->Y, VG_EINVAL);
+    VG_CHECK_ARG(d->B > 0 && d->GH > 0 && d->GW > 0 && d->IH > 0 && d->IW > 0 && d->IC > 0, VG_EINVAL);
+    VG_CHECK_ARG(d->N > 0 && d->OC >= d->N && d->OH > 0 && d->OW > 0, VG_EINVAL);
+    VG_CHECK_ARG(d->TH > 0 && d->TW > 0 && d->nphase >= 1 && d->nphase <= VG_MAX_PHASE, VG_EINVAL);
+    VG_CHECK_ARG((d->IC * esz) % 16 == 0, VG_EALIGN);
+    VG_CHECK_ARG((d->Kp * esz) % 64 == 0 && d->Kp >= d->TH * d->TW * d->IC, VG_EALIGN);
+    VG_CHECK_ARG(vg_aligned16(d->X) && vg_aligned16(d->W), VG_EALIGN);
+    VG_CHECK_ARG((int64_t)d->B * d->GH * d->GW < (1ll << 31), VG_EINVAL);
+    VG_CHECK_ARG((int64_t)d->B * d->IH * d->IW < (1ll << 31), VG_EINVAL);
+    // every output pixel written by some phase must be inside the tensor (skips are allowed)
+    for (int p = 0; p < d->nphase; ++p) VG_CHECK_ARG(d->ooy[p] >= 0 && d->oox[p] >= 0, VG_EINVAL);
+    return 0;
+}
+
+template <int DT, int BM, int BN, int WM, int WN>
+int launch(const vg_gg_desc* d, hipStream_t s) {
+    const int M = d->B * d->GH * d->GW;
+    dim3 grid((M + BM - 1) / BM, (d->N + BN - 1) / BN, d->nphase);
+    hipLaunchKernelGGL((gg_kernel<DT, BM, BN, WM, WN>), grid, dim3(256), 0, s, *d);
+    return VG_LAUNCH_RC();
+}
+
+template <int DT>
+int dispatch(const vg_gg_desc* d, TileCfg t, hipStream_t s) {
+    if (t.bm == 256 && t.bn == 16) return launch<DT, 256, 16, 4, 1>(d, s);
+    if (t.bm == 128 && t.bn == 32) return launch<DT, 128, 32, 4, 1>(d, s);
+    if (t.bm == 128 && t.bn == 128) return launch<DT, 128, 128, 2, 2>(d, s);
+    if (t.bm == 128 && t.bn == 64) return launch<DT, 128, 64, 2, 2>(d, s);
+    return launch<DT, 64, 64, 2, 2>(d, s);
+}
+
+}  // namespace
+
+extern "C" int vg_gather_gemm_nparts(const vg_gg_desc* d, int dtype) {
+    int rc = validate(d, dtype);
+    if (rc) return rc;
+    TileCfg t = pick_tile(d);
+    const int M = d->B * d->GH * d->GW;
+    return d->nphase * ((M + t.bm - 1) / t.bm);
+}
+
+extern "C" int vg_gather_gemm(const vg_gg_desc* d, int dtype, void* stream) {
+    int rc = validate(d, dtype);
+    if (rc) return rc;
+    TileCfg t = pick_tile(d);
+    if (d->stats) {
+        const int M = d->B * d->GH * d->GW;
+        VG_CHECK_ARG(d->stats_capacity >= d->nphase * ((M + t.bm - 1) / t.bm), VG_EINVAL);
+    }
+    if (dtype == VG_F32) return dispatch<VG_F32>(d, t, vg_stream(stream));
+    return dispatch<VG_BF16>(d, t, vg_stream(stream));
+}

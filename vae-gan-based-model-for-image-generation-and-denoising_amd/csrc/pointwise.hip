@@ -1,0 +1,363 @@
+// Layout changes at the NCHW boundary, instance noise, reparameterisation + KL, the
+// Discriminator's 1-channel head, and the BCE / MSE losses (vaegan_code.py:74-78, 88-117).
+// All of these are HBM- or latency-bound pointwise / small-reduction kernels.
+#include "common.hpp"
+
+namespace {
+
+// ---- NCHW f32  <->  NHWC (dtype, channels padded to CP) ----------------------------------------
+template <int DT>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, const float* __restrict__ eps,
+                                                           float sigma, void* __restrict__ y, int64_t npix, int C,
+                                                           int HW, int CP) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / HW;
+        const int64_t hw = i - b * HW;
+        for (int c = 0; c < CP; ++c) {
+            float v = 0.f;
+            if (c < C) {
+                const int64_t src = (b * C + c) * HW + hw;
+                v = x[src];
+                if (eps) v = v + sigma * eps[src];
+            }
+            store1<DT>(y, i * CP + c, v);
+        }
+    }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const void* __restrict__ x, float* __restrict__ y,
+                                                           int64_t npix, int C, int HW, int CP, int apply_tanh) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / HW;
+        const int64_t hw = i - b * HW;
+        for (int c = 0; c < C; ++c) {
+            float v = load1<DT>(x, i * CP + c);
+            if (apply_tanh) v = tanhf(v);
+            y[(b * C + c) * HW + hw] = v;
+        }
+    }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void nchw_grad_to_nhwc_kernel(const float* __restrict__ dy,
+                                                                const float* __restrict__ t, void* __restrict__ dx,
+                                                                int64_t npix, int C, int HW, int CP) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / HW;
+        const int64_t hw = i - b * HW;
+        for (int c = 0; c < CP; ++c) {
+            float v = 0.f;
+            if (c < C) {
+                const int64_t src = (b * C + c) * HW + hw;
+                v = dy[src];
+                if (t) { const float tv = t[src]; v = v * (1.f - tv * tv); }
+            }
+            store1<DT>(dx, i * CP + c, v);
+        }
+    }
+}
+
+// ---- reparameterisation / KL ----------------------------------------------------------------------
+template <int DT>
+__global__ void reparam_fwd_kernel(const void* __restrict__ mulv, const float* __restrict__ eps, void* __restrict__ z,
+                                   float* __restrict__ lvc, int B, int L, int MP, int ZP) {
+    const int total = B * ZP;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int b = i / ZP, j = i - b * ZP;
+        float zv = 0.f;
+        if (j < L) {
+            const float mu = load1<DT>(mulv, (int64_t)b * MP + j);
+            float lv = load1<DT>(mulv, (int64_t)b * MP + L + j);
+            lv = fminf(fmaxf(lv, -10.f), 10.f);
+            lvc[b * L + j] = lv;
+            zv = mu + expf(0.5f * lv) * eps[b * L + j];
+        }
+        store1<DT>(z, i, zv);
+    }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void kl_kernel(const void* __restrict__ mulv, const float* __restrict__ lvc, int B,
+                                                 int L, int MP, float divisor, float* __restrict__ out) {
+    __shared__ double red[4];
+    double s = 0.0;
+    const int total = B * L;
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+        const int b = i / L, j = i - b * L;
+        const float mu = load1<DT>(mulv, (int64_t)b * MP + j);
+        const float lv = lvc[i];
+        s += (double)(1.f + lv - mu * mu - expf(lv));
+    }
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (float)(-0.5 * (red[0] + red[1] + red[2] + red[3])) / divisor;
+}
+
+template <int DT>
+__global__ void reparam_kl_bwd_kernel(const void* __restrict__ mulv, const float* __restrict__ lvc,
+                                      const float* __restrict__ eps, const void* __restrict__ dz, float kl_scale,
+                                      void* __restrict__ dmulv, int B, int L, int MP, int ZP) {
+    const int total = B * MP;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int b = i / MP, j = i - b * MP;
+        float g = 0.f;
+        if (j < L) {                                   // d mu = dz + kl_scale * mu
+            const float mu = load1<DT>(mulv, (int64_t)b * MP + j);
+            g = load1<DT>(dz, (int64_t)b * ZP + j) + kl_scale * mu;
+        } else if (j < 2 * L) {                        // d logvar (through the clamp, inclusive bounds)
+            const int jj = j - L;
+            const float raw = load1<DT>(mulv, (int64_t)b * MP + j);
+            if (raw >= -10.f && raw <= 10.f) {
+                const float lv = lvc[b * L + jj];
+                const float d = load1<DT>(dz, (int64_t)b * ZP + jj);
+                g = d * (0.5f * expf(0.5f * lv) * eps[b * L + jj]) + kl_scale * 0.5f * (expf(lv) - 1.f);
+            }
+        }
+        store1<DT>(dmulv, i, g);
+    }
+}
+
+// ---- Discriminator head: Conv2d(C,1,k=HxW) + Sigmoid on the final feature map -------------------
+template <int DT>
+__global__ __launch_bounds__(256) void dot_sigmoid_fwd_kernel(const void* __restrict__ x, const void* __restrict__ w,
+                                                              float* __restrict__ p, int B, int K) {
+    // one wave per image
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (wave >= B) return;
+    float s = 0.f;
+    for (int k = lane * 4; k < K; k += 256) {
+        const float4 a = load4<DT>(x, (int64_t)wave * K + k);
+        const float4 b = load4<DT>(w, k);
+        s += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+    }
+    s = wave_sum(s);
+    if (lane == 0) p[wave] = 1.f / (1.f + expf(-s));
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void dot_sigmoid_bwd_kernel(const float* __restrict__ p, const float* __restrict__ dp,
+                                                              const void* __restrict__ w, void* __restrict__ dx,
+                                                              float* __restrict__ dlogit, int B, int K) {
+    const int64_t nvec = (int64_t)B * K / 4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+        const int b = (int)((i * 4) / K);
+        const int k = (int)((i * 4) - (int64_t)b * K);
+        const float pv = p[b];
+        const float dl = dp[b] * (pv * (1.f - pv));          // sigmoid_backward: grad * (1 - y) * y
+        if (k == 0) dlogit[b] = dl;
+        if (dx) {
+            float4 wv = load4<DT>(w, k);
+            wv.x *= dl; wv.y *= dl; wv.z *= dl; wv.w *= dl;
+            store4<DT>(dx, i * 4, wv);
+        }
+    }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void dot_wgrad_kernel(const void* __restrict__ x, const float* __restrict__ dlogit,
+                                                        float* __restrict__ dw, int B, int K, int C, int HW,
+                                                        int accumulate) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;      // NHWC-flattened index (hw*C + c)
+    if (k >= K) return;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += dlogit[b] * load1<DT>(x, (int64_t)b * K + k);
+    const int hw = k / C, c = k - hw * C;
+    float* dst = dw + (int64_t)c * HW + hw;                   // reference layout [1][C][kh][kw]
+    *dst = accumulate ? (*dst + s) : s;
+}
+
+// ---- losses -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bce_kernel(const float* __restrict__ p, float target, int B, float gscale,
+                                                  float* __restrict__ loss, int accumulate, float* __restrict__ dp) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const float pv = p[b];
+        const float l1 = fmaxf(logf(pv), -100.f);
+        const float l2 = fmaxf(logf(1.f - pv), -100.f);
+        s += (double)(-(target * l1 + (1.f - target) * l2));
+        if (dp) dp[b] = gscale * ((pv - target) / fmaxf((1.f - pv) * pv, 1e-12f)) / (float)B;
+    }
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float v = (float)((red[0] + red[1] + red[2] + red[3]) / (double)B);
+        loss[0] = accumulate ? loss[0] + v : v;
+    }
+}
+
+__global__ __launch_bounds__(256) void mse_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                          int64_t n, float gcoef, float* __restrict__ d_a,
+                                                          float* __restrict__ ws) {
+    __shared__ double red[4];
+    double s = 0.0;
+    const int64_t n4 = n / 4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 x = reinterpret_cast<const float4*>(a)[i];
+        const float4 y = reinterpret_cast<const float4*>(b)[i];
+        float4 d;
+        d.x = x.x - y.x; d.y = x.y - y.y; d.z = x.z - y.z; d.w = x.w - y.w;
+        s += (double)(d.x * d.x) + (double)(d.y * d.y) + (double)(d.z * d.z) + (double)(d.w * d.w);
+        if (d_a) {
+            d.x *= gcoef; d.y *= gcoef; d.z *= gcoef; d.w *= gcoef;
+            reinterpret_cast<float4*>(d_a)[i] = d;
+        }
+    }
+    if (blockIdx.x == 0) {
+        for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) {
+            const float d = a[i] - b[i];
+            s += (double)(d * d);
+            if (d_a) d_a[i] = d * gcoef;
+        }
+    }
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) ws[blockIdx.x] = (float)(red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ void mse_final_kernel(const float* __restrict__ ws, int nparts, double n, float* __restrict__ loss) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 64) s += (double)ws[i];
+    s = wave_sum_d(s);
+    if (threadIdx.x == 0) loss[0] = (float)(s / n);
+}
+
+__global__ __launch_bounds__(256) void axpy_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                   float alpha, float* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = a[i] + alpha * b[i];
+}
+
+inline int blocks_for(int64_t n, int cap = 4096) {
+    int64_t b = (n + 255) / 256;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace
+
+#define DISPATCH_DT(KERNEL, GRID, BLOCK, STREAM, ...)                                              \
+    do {                                                                                           \
+        if (dtype == VG_F32) hipLaunchKernelGGL(KERNEL<VG_F32>, GRID, BLOCK, 0, STREAM, __VA_ARGS__);   \
+        else hipLaunchKernelGGL(KERNEL<VG_BF16>, GRID, BLOCK, 0, STREAM, __VA_ARGS__);                  \
+    } while (0)
+
+#define CHECK_DT() VG_CHECK_ARG(dtype == VG_F32 || dtype == VG_BF16, VG_ENOSUP)
+
+extern "C" int vg_nchw_to_nhwc(const float* x, const float* eps, float sigma, void* y, int B, int C, int H, int W,
+                               int CP, int dtype, void* stream) {
+    CHECK_DT();
+    VG_CHECK_ARG(x && y && B > 0 && C > 0 && H > 0 && W > 0 && CP >= C, VG_EINVAL);
+    const int64_t npix = (int64_t)B * H * W;
+    DISPATCH_DT(nchw_to_nhwc_kernel, dim3(blocks_for(npix)), dim3(256), vg_stream(stream), x, eps, sigma, y, npix, C,
+                H * W, CP);
+    return VG_LAUNCH_RC();
+}
+
+extern "C" int vg_nhwc_to_nchw(const void* x, float* y, int B, int C, int H, int W, int CP, int apply_tanh, int dtype,
+                               void* stream) {
+    CHECK_DT();
+    VG_CHECK_ARG(x && y && B > 0 && C > 0 && H > 0 && W > 0 && CP >= C, VG_EINVAL);
+    const int64_t npix = (int64_t)B * H * W;
+    DISPATCH_DT(nhwc_to_nchw_kernel, dim3(blocks_for(npix)), dim3(256), vg_stream(stream), x, y, npix, C, H * W, CP,
+                apply_tanh);
+    return VG_LAUNCH_RC();
+}
+
+extern "C" int vg_nchw_grad_to_nhwc(const float* dy, const float* tanh_out, void* dx, int B, int C, int H, int W,
+                                    int CP, int dtype, void* stream) {
+    CHECK_DT();
+    VG_CHECK_ARG(dy && dx && B > 0 && C > 0 && H > 0 && W > 0 && CP >= C, VG_EINVAL);
+    const int64_t npix = (int64_t)B * H * W;
+    DISPATCH_DT(nchw_grad_to_nhwc_kernel, dim3(blocks_for(npix)), dim3(256), vg_stream(stream), dy, tanh_out, dx, npix,
+                C, H * W, CP);
+    return VG_LAUNCH_RC();
+}
+
+extern "C" int vg_reparam_forward(const void* mulv, const float* eps, void* z, float* lv_clamped, int B, int L, int MP,
+                                  int ZP, int dtype, void* stream) {
+    CHECK_DT();
+    VG_CHECK_ARG(mulv && eps && z && lv_clamped && B > 0 && L > 0 && MP >= 2 * L && ZP >= L, VG_EINVAL);
+    DISPATCH_DT(reparam_fwd_kernel, dim3(blocks_for((int64_t)B * ZP)), dim3(256), vg_stream(stream), mulv, eps, z,
+                lv_clamped, B, L, MP, ZP);
+    return VG_LAUNCH_RC();
+}
+
+extern "C" int vg_kl_forward(const void* mulv, const float* lv_clamped, int B, int L, int MP, float divisor, float* out,
+                             int dtype, void* stream) {
+    CHECK_DT();
+    VG_CHECK_ARG(mulv && lv_clamped && out && B > 0 && L > 0 && MP >= 2 * L && divisor != 0.f, VG_EINVAL);
+    DISPATCH_DT(kl_kernel, dim3(1), dim3(256), vg_stream(stream), mulv, lv_clamped, B, L, MP, divisor, out);
+    return VG_LAUNCH_RC();
+}
+
+extern "C" int vg_reparam_kl_backward(const void* mulv, const float* lv_clamped, const float* eps, const void* dz,
+                                      float kl_scale, void* dmulv, int B, int L, int MP, int ZP, int dtype,
+                                      void* stream) {
+    CHECK_DT();
+    VG_CHECK_ARG(mulv && lv_clamped && eps && dz && dmulv && B > 0 && L > 0 && MP >= 2 * L && ZP >= L, VG_EINVAL);
+    DISPATCH_DT(reparam_kl_bwd_kernel, dim3(blocks_for((int64_t)B * MP)), dim3(256), vg_stream(stream), mulv,
+                lv_clamped, eps, dz, kl_scale, dmulv, B, L, MP, ZP);
+    return VG_LAUNCH_RC();
+}
+
+extern "C" int vg_dot_sigmoid_forward(const void* x, const void* w, float* p, int B, int K, int dtype, void* stream) {
+    CHECK_DT();
+    VG_CHECK_ARG(x && w && p && B > 0 && K > 0 && K % 4 == 0, VG_EINVAL);
+    DISPATCH_DT(dot_sigmoid_fwd_kernel, dim3((B + 3) / 4), dim3(256), vg_stream(stream), x, w, p, B, K);
+    return VG_LAUNCH_RC();
+}
+
+extern "C" int vg_dot_sigmoid_backward(const float* p, const float* dp, const void* w, void* dx, float* dlogit, int B,
+                                       int K, int dtype, void* stream) {
+    CHECK_DT();
+    VG_CHECK_ARG(p && dp && w && dlogit && B > 0 && K > 0 && K % 4 == 0, VG_EINVAL);
+    DISPATCH_DT(dot_sigmoid_bwd_kernel, dim3(blocks_for((int64_t)B * K / 4)), dim3(256), vg_stream(stream), p, dp, w, dx,
+                dlogit, B, K);
+    return VG_LAUNCH_RC();
+}
+
+extern "C" int vg_dot_wgrad(const void* x, const float* dlogit, float* dw, int B, int K, int C, int HW, int accumulate,
+                            int dtype, void* stream) {
+    CHECK_DT();
+    VG_CHECK_ARG(x && dlogit && dw && B > 0 && K > 0 && C > 0 && HW > 0 && C * HW == K, VG_EINVAL);
+    DISPATCH_DT(dot_wgrad_kernel, dim3((K + 255) / 256), dim3(256), vg_stream(stream), x, dlogit, dw, B, K, C, HW,
+                accumulate);
+    return VG_LAUNCH_RC();
+}
+
+extern "C" int vg_bce_forward_backward(const float* p, float target, int B, float gscale, float* loss, int accumulate,
+                                       float* dp, void* stream) {
+    VG_CHECK_ARG(p && loss && B > 0, VG_EINVAL);
+    hipLaunchKernelGGL(bce_kernel, dim3(1), dim3(256), 0, vg_stream(stream), p, target, B, gscale, loss, accumulate, dp);
+    return VG_LAUNCH_RC();
+}
+
+extern "C" int vg_mse_forward_backward(const float* a, const float* b, int64_t n, float gscale, float* loss, float* d_a,
+                                       float* ws, int ws_capacity, void* stream) {
+    VG_CHECK_ARG(a && b && loss && ws && n > 0 && ws_capacity >= 1, VG_EINVAL);
+    VG_CHECK_ARG(vg_aligned16(a) && vg_aligned16(b) && (d_a == nullptr || vg_aligned16(d_a)), VG_EALIGN);
+    int blocks = blocks_for(n / 4, 1024);
+    if (blocks > ws_capacity) blocks = ws_capacity;
+    const float gcoef = (float)((double)gscale * 2.0 / (double)n);
+    hipLaunchKernelGGL(mse_partial_kernel, dim3(blocks), dim3(256), 0, vg_stream(stream), a, b, n, gcoef, d_a, ws);
+    int rc = VG_LAUNCH_RC();
+    if (rc) return rc;
+    hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(64), 0, vg_stream(stream), ws, blocks, (double)n, loss);
+    return VG_LAUNCH_RC();
+}
+
+extern "C" int vg_axpy(const float* a, const float* b, float alpha, float* out, int64_t n, void* stream) {
+    VG_CHECK_ARG(a && b && out && n > 0, VG_EINVAL);
+    hipLaunchKernelGGL(axpy_kernel, dim3(blocks_for(n)), dim3(256), 0, vg_stream(stream), a, b, alpha, out, n);
+    return VG_LAUNCH_RC();
+}
+
+extern "C" int vg_abi_version(void) { return 1; }
+extern "C" const char* vg_build_info(void) { return "vaegan_hip gfx950: gather-GEMM f32(16x16x4)/bf16(16x16x32) MFMA"; }

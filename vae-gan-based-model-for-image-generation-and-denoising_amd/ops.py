@@ -1,0 +1,298 @@
+"""Thin tensor-level wrappers over the C ABI (libvaegan_hip.so).
+
+Each function takes torch CUDA tensors (used only as device-memory handles), fills the
+descriptor struct, and launches on torch's current HIP stream.  No computation happens in
+Python/ATen here.  All functions raise RuntimeError when the library rejects the arguments.
+"""
+from ctypes import byref, c_int
+
+import torch
+
+from . import _lib as L
+from .geometry import BF16, F32, GGSpec, PackSpec, WGSpec, esize
+
+TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16}
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("vaegan_amd ops need tensors on the MI355X (cuda) device; there is no CPU path")
+        if t is not None and not t.is_contiguous():
+            raise RuntimeError("vaegan_amd ops need contiguous tensors")
+
+
+class _Workspace:
+    """Grow-only scratch buffers, one per (device, tag); all users are ordered on one stream."""
+
+    def __init__(self):
+        self.bufs = {}
+
+    def get(self, tag: str, nbytes: int, device) -> torch.Tensor:
+        key = (tag, str(device))
+        buf = self.bufs.get(key)
+        if buf is None or buf.numel() * 4 < nbytes:
+            n = max(int(nbytes * 1.25) // 4 + 64, 1 << 16)
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError(f"workspace '{tag}' would grow during graph capture; run a warm-up step first")
+            buf = torch.empty(n, dtype=torch.float32, device=device)
+            self.bufs[key] = buf
+        return buf
+
+
+WS = _Workspace()
+
+
+def empty_act(shape, dtype: int, device) -> torch.Tensor:
+    return torch.empty(shape, dtype=TORCH_DT[dtype], device=device)
+
+
+# ---------------------------------------------------------------------------------------------
+def pack_weights(pk: PackSpec, w: torch.Tensor, dtype: int, out: torch.Tensor = None) -> torch.Tensor:
+    _need_cuda(w, out)
+    if w.dtype != torch.float32:
+        raise RuntimeError("parameters must be float32 (fp32 master weights)")
+    if out is None:
+        out = torch.empty(pk.numel(), dtype=TORCH_DT[dtype], device=w.device)
+    d = L.PackDesc(src=w.data_ptr(), dst=out.data_ptr(), nphase=pk.nphase, N=pk.N, C=pk.C, IC=pk.IC, TH=pk.TH,
+                   TW=pk.TW, Kp=pk.Kp, s_n=pk.s_n, s_c=pk.s_c, KW=pk.KW, kh0=L.i4(pk.kh0), kw0=L.i4(pk.kw0),
+                   kh_step=pk.kh_step, kw_step=pk.kw_step, tap_in_n=pk.tap_in_n, KHW=pk.KHW)
+    L.check(L.load().vg_pack_weights(byref(d), dtype, L.stream_ptr()), "vg_pack_weights")
+    return out
+
+
+def _gg_desc(g: GGSpec, X, Wp, Y, bias, stats, cap) -> L.GGDesc:
+    return L.GGDesc(X=X.data_ptr(), W=Wp.data_ptr(), Y=Y.data_ptr(),
+                    bias=0 if bias is None else bias.data_ptr(), stats=0 if stats is None else stats.data_ptr(),
+                    B=g.B, GH=g.GH, GW=g.GW, IH=g.IH, IW=g.IW, IC=g.IC, SY=g.SY, SX=g.SX, DY=g.DY, DX=g.DX,
+                    TH=g.TH, TW=g.TW, y0=L.i4(g.y0), x0=L.i4(g.x0), N=g.N, Kp=g.Kp, OH=g.OH, OW=g.OW, OC=g.OC,
+                    OSY=g.OSY, OSX=g.OSX, ooy=L.i4(g.ooy), oox=L.i4(g.oox), nphase=g.nphase, stats_capacity=cap)
+
+
+def gather_gemm(g: GGSpec, X: torch.Tensor, Wp: torch.Tensor, dtype: int, bias: torch.Tensor = None,
+                want_stats: bool = False, out: torch.Tensor = None):
+    """Returns (Y [B,OH,OW,OC], stats slabs or None, nparts)."""
+    _need_cuda(X, Wp, bias, out)
+    if X.dtype != TORCH_DT[dtype] or Wp.dtype != TORCH_DT[dtype]:
+        raise RuntimeError(f"gather_gemm: operand dtype {X.dtype}/{Wp.dtype} does not match engine dtype")
+    if X.numel() != g.B * g.IH * g.IW * g.IC:
+        raise RuntimeError(f"gather_gemm: input has {X.numel()} elements, geometry expects "
+                           f"{(g.B, g.IH, g.IW, g.IC)}")
+    if Wp.numel() != g.nphase * g.N * g.Kp:
+        raise RuntimeError("gather_gemm: packed weight size mismatch")
+    lib = L.load()
+    Y = out if out is not None else empty_act((g.B, g.OH, g.OW, g.OC), dtype, X.device)
+    if Y.numel() != g.B * g.OH * g.OW * g.OC:
+        raise RuntimeError("gather_gemm: output size mismatch")
+    stats, nparts = None, 0
+    if want_stats:
+        probe = _gg_desc(g, X, Wp, Y, bias, None, 0)
+        nparts = lib.vg_gather_gemm_nparts(byref(probe), dtype)
+        if nparts < 0:
+            L.check(nparts, "vg_gather_gemm_nparts")
+        stats = WS.get("stats", nparts * 2 * g.N * 4, X.device)
+    d = _gg_desc(g, X, Wp, Y, bias, stats, nparts)
+    L.check(lib.vg_gather_gemm(byref(d), dtype, L.stream_ptr()), "vg_gather_gemm")
+    return Y, stats, nparts
+
+
+def wgrad(wg: WGSpec, P: torch.Tensor, Q: torch.Tensor, dW: torch.Tensor, accumulate: bool, dtype: int) -> None:
+    _need_cuda(P, Q, dW)
+    if dW.dtype != torch.float32:
+        raise RuntimeError("weight gradients are float32")
+    if P.numel() != wg.B * wg.GH * wg.GW * wg.PC or Q.numel() != wg.B * wg.QH * wg.QW * wg.QC:
+        raise RuntimeError("wgrad: operand size mismatch")
+    lib = L.load()
+    d = L.WGDesc(P=P.data_ptr(), Q=Q.data_ptr(), dW=dW.data_ptr(), ws=0, ws_bytes=0, B=wg.B, GH=wg.GH, GW=wg.GW,
+                 PC=wg.PC, NP=wg.NP, QH=wg.QH, QW=wg.QW, QC=wg.QC, NQ=wg.NQ, SY=wg.SY, SX=wg.SX, DY=wg.DY,
+                 DX=wg.DX, TH=wg.TH, TW=wg.TW, y0=wg.y0, x0=wg.x0, s_np=wg.s_np, s_cq=wg.s_cq, s_t=wg.s_t,
+                 accumulate=1 if accumulate else 0)
+    nbytes = lib.vg_wgrad_ws_bytes(byref(d), dtype)
+    if nbytes < 0:
+        L.check(int(nbytes), "vg_wgrad_ws_bytes")
+    ws = WS.get("wgrad", nbytes, P.device)
+    d.ws = ws.data_ptr()
+    d.ws_bytes = ws.numel() * 4
+    L.check(lib.vg_wgrad(byref(d), dtype, L.stream_ptr()), "vg_wgrad")
+
+
+# ---------------------------------------------------------------------------------------------
+def bn_finalize(stats, nparts, C, count, gamma, beta, running_mean, running_var, momentum, eps, device):
+    """-> coeffs tensor [4][C]: mean, invstd, scale, shift."""
+    co = torch.empty(4, C, dtype=torch.float32, device=device)
+    L.check(L.load().vg_bn_finalize(L.ptr(stats), nparts, C, count, L.ptr(gamma), L.ptr(beta), L.ptr(running_mean),
+                                    L.ptr(running_var), momentum, eps, co[0].data_ptr(), co[1].data_ptr(),
+                                    co[2].data_ptr(), co[3].data_ptr(), L.stream_ptr()), "vg_bn_finalize")
+    return co
+
+
+def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps):
+    C = running_mean.numel()
+    co = torch.empty(4, C, dtype=torch.float32, device=running_mean.device)
+    L.check(L.load().vg_bn_eval_coeffs(L.ptr(gamma), L.ptr(beta), L.ptr(running_mean), L.ptr(running_var), eps, C,
+                                       co[2].data_ptr(), co[3].data_ptr(), L.stream_ptr()), "vg_bn_eval_coeffs")
+    return co
+
+
+def bn_act_forward(x, coeffs, rows, C, act, slope, dtype, out=None):
+    _need_cuda(x, coeffs)
+    y = out if out is not None else torch.empty_like(x)
+    sc = coeffs[2].data_ptr() if coeffs is not None else 0
+    sh = coeffs[3].data_ptr() if coeffs is not None else 0
+    L.check(L.load().vg_bn_act_forward(x.data_ptr(), y.data_ptr(), sc, sh, rows, C, act, slope, dtype,
+                                       L.stream_ptr()), "vg_bn_act_forward")
+    return y
+
+
+def channel_stats(x, rows, C, dtype):
+    n = c_int(0)
+    cap = 1024
+    stats = WS.get("stats", cap * 2 * C * 4, x.device)
+    L.check(L.load().vg_channel_stats(x.data_ptr(), rows, C, stats.data_ptr(), cap, byref(n), dtype, L.stream_ptr()),
+            "vg_channel_stats")
+    return stats, n.value
+
+
+def bn_act_backward(x, dy, coeffs, rows, C, count, gamma, act, slope, dgamma, dbeta, accumulate, dtype):
+    """Full BN(+act) backward: returns dx (gradient w.r.t. the raw conv output)."""
+    _need_cuda(x, dy, coeffs)
+    lib = L.load()
+    n = c_int(0)
+    cap = 1024
+    partial = WS.get("bnbwd", cap * 2 * C * 4, x.device)
+    L.check(lib.vg_bn_act_backward_reduce(x.data_ptr(), dy.data_ptr(), coeffs[2].data_ptr(), coeffs[3].data_ptr(),
+                                          coeffs[0].data_ptr(), coeffs[1].data_ptr(), rows, C, act, slope,
+                                          partial.data_ptr(), cap, byref(n), dtype, L.stream_ptr()),
+            "vg_bn_act_backward_reduce")
+    coef = torch.empty(3, C, dtype=torch.float32, device=x.device)
+    L.check(lib.vg_bn_backward_finalize(partial.data_ptr(), n.value, C, count, L.ptr(gamma), coeffs[1].data_ptr(),
+                                        L.ptr(dgamma), L.ptr(dbeta), 1 if accumulate else 0, coef.data_ptr(),
+                                        L.stream_ptr()), "vg_bn_backward_finalize")
+    dx = torch.empty_like(x)
+    L.check(lib.vg_bn_act_backward_apply(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), coeffs[2].data_ptr(),
+                                         coeffs[3].data_ptr(), coeffs[0].data_ptr(), coeffs[1].data_ptr(),
+                                         coef.data_ptr(), rows, C, act, slope, dtype, L.stream_ptr()),
+            "vg_bn_act_backward_apply")
+    return dx
+
+
+def act_backward(x, dy, act, slope, dtype):
+    dx = torch.empty_like(x)
+    L.check(L.load().vg_act_backward(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.numel(), act, slope, dtype,
+                                     L.stream_ptr()), "vg_act_backward")
+    return dx
+
+
+def bias_grad(dy, rows, C, NC, dbias, accumulate, dtype):
+    cap = 1024
+    ws = WS.get("bnbwd", cap * 2 * C * 4, dy.device)
+    L.check(L.load().vg_bias_grad(dy.data_ptr(), rows, C, NC, dbias.data_ptr(), 1 if accumulate else 0,
+                                  ws.data_ptr(), cap, dtype, L.stream_ptr()), "vg_bias_grad")
+
+
+# ---------------------------------------------------------------------------------------------
+def nchw_to_nhwc(x, CP, dtype, eps=None, sigma=0.0):
+    _need_cuda(x, eps)
+    B, C, H, W = x.shape
+    y = empty_act((B, H, W, CP), dtype, x.device)
+    L.check(L.load().vg_nchw_to_nhwc(x.data_ptr(), L.ptr(eps), sigma, y.data_ptr(), B, C, H, W, CP, dtype,
+                                     L.stream_ptr()), "vg_nchw_to_nhwc")
+    return y
+
+
+def nhwc_to_nchw(x, C, dtype, apply_tanh=False):
+    _need_cuda(x)
+    B, H, W, CP = x.shape
+    y = torch.empty(B, C, H, W, dtype=torch.float32, device=x.device)
+    L.check(L.load().vg_nhwc_to_nchw(x.data_ptr(), y.data_ptr(), B, C, H, W, CP, 1 if apply_tanh else 0, dtype,
+                                     L.stream_ptr()), "vg_nhwc_to_nchw")
+    return y
+
+
+def nchw_grad_to_nhwc(dy, tanh_out, CP, dtype):
+    _need_cuda(dy, tanh_out)
+    B, C, H, W = dy.shape
+    dx = empty_act((B, H, W, CP), dtype, dy.device)
+    L.check(L.load().vg_nchw_grad_to_nhwc(dy.data_ptr(), L.ptr(tanh_out), dx.data_ptr(), B, C, H, W, CP, dtype,
+                                          L.stream_ptr()), "vg_nchw_grad_to_nhwc")
+    return dx
+
+
+def reparam_forward(mulv, eps, L_dim, ZP, dtype):
+    _need_cuda(mulv, eps)
+    B, MP = mulv.shape[0], mulv.shape[-1]
+    z = empty_act((B, 1, 1, ZP), dtype, mulv.device)
+    lvc = torch.empty(B, L_dim, dtype=torch.float32, device=mulv.device)
+    L.check(L.load().vg_reparam_forward(mulv.data_ptr(), eps.data_ptr(), z.data_ptr(), lvc.data_ptr(), B, L_dim, MP,
+                                        ZP, dtype, L.stream_ptr()), "vg_reparam_forward")
+    return z, lvc
+
+
+def kl_forward(mulv, lvc, L_dim, divisor, dtype, out=None):
+    B, MP = mulv.shape[0], mulv.shape[-1]
+    out = out if out is not None else torch.empty(1, dtype=torch.float32, device=mulv.device)
+    L.check(L.load().vg_kl_forward(mulv.data_ptr(), lvc.data_ptr(), B, L_dim, MP, divisor, out.data_ptr(), dtype,
+                                   L.stream_ptr()), "vg_kl_forward")
+    return out
+
+
+def reparam_kl_backward(mulv, lvc, eps, dz, kl_scale, L_dim, dtype):
+    B, MP = mulv.shape[0], mulv.shape[-1]
+    ZP = dz.shape[-1]
+    dmulv = torch.empty_like(mulv)
+    L.check(L.load().vg_reparam_kl_backward(mulv.data_ptr(), lvc.data_ptr(), eps.data_ptr(), dz.data_ptr(), kl_scale,
+                                            dmulv.data_ptr(), B, L_dim, MP, ZP, dtype, L.stream_ptr()),
+            "vg_reparam_kl_backward")
+    return dmulv
+
+
+def dot_sigmoid_forward(x, w, B, K, dtype):
+    p = torch.empty(B, dtype=torch.float32, device=x.device)
+    L.check(L.load().vg_dot_sigmoid_forward(x.data_ptr(), w.data_ptr(), p.data_ptr(), B, K, dtype, L.stream_ptr()),
+            "vg_dot_sigmoid_forward")
+    return p
+
+
+def dot_sigmoid_backward(p, dp, w, B, K, dtype, need_dx, like):
+    dlogit = torch.empty(B, dtype=torch.float32, device=p.device)
+    dx = torch.empty_like(like) if need_dx else None
+    L.check(L.load().vg_dot_sigmoid_backward(p.data_ptr(), dp.data_ptr(), w.data_ptr(), L.ptr(dx), dlogit.data_ptr(),
+                                             B, K, dtype, L.stream_ptr()), "vg_dot_sigmoid_backward")
+    return dx, dlogit
+
+
+def dot_wgrad(x, dlogit, dw, B, K, C, HW, accumulate, dtype):
+    L.check(L.load().vg_dot_wgrad(x.data_ptr(), dlogit.data_ptr(), dw.data_ptr(), B, K, C, HW,
+                                  1 if accumulate else 0, dtype, L.stream_ptr()), "vg_dot_wgrad")
+
+
+def bce_forward_backward(p, target, gscale, loss, accumulate, want_grad):
+    _need_cuda(p, loss)
+    B = p.numel()
+    dp = torch.empty_like(p) if want_grad else None
+    L.check(L.load().vg_bce_forward_backward(p.data_ptr(), target, B, gscale, loss.data_ptr(),
+                                             1 if accumulate else 0, L.ptr(dp), L.stream_ptr()),
+            "vg_bce_forward_backward")
+    return dp
+
+
+def mse_forward_backward(a, b, gscale, loss, want_grad):
+    _need_cuda(a, b, loss)
+    n = a.numel()
+    da = torch.empty_like(a) if want_grad else None
+    ws = WS.get("mse", 1024 * 4, a.device)
+    L.check(L.load().vg_mse_forward_backward(a.data_ptr(), b.data_ptr(), n, gscale, loss.data_ptr(), L.ptr(da),
+                                             ws.data_ptr(), 1024, L.stream_ptr()), "vg_mse_forward_backward")
+    return da
+
+
+def axpy(a, b, alpha, out=None):
+    out = out if out is not None else torch.empty_like(a)
+    L.check(L.load().vg_axpy(a.data_ptr(), b.data_ptr(), alpha, out.data_ptr(), a.numel(), L.stream_ptr()), "vg_axpy")
+    return out
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, grad_scale, state):
+    _need_cuda(p, g, m, v, state)
+    L.check(L.load().vg_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1,
+                                  beta2, eps, grad_scale, state.data_ptr(), L.stream_ptr()), "vg_adam_step")

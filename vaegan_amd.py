@@ -1,0 +1,11 @@
+"""Import alias: ``import vaegan_amd`` -> the package directory
+``vae-gan-based-model-for-image-generation-and-denoising_amd`` (not a valid identifier)."""
+import importlib
+import os
+import sys
+
+_here = os.path.dirname(os.path.abspath(__file__))
+if _here not in sys.path:
+    sys.path.insert(0, _here)
+_pkg = importlib.import_module("vae-gan-based-model-for-image-generation-and-denoising_amd")
+sys.modules[__name__] = _pkg
