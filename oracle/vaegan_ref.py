@@ -274,17 +274,35 @@ class RefVAEGAN:
         self.opt_G = RefAdam(require_grads(self.G), lr=lr)                      # :43
         self.opt_D = RefAdam(require_grads(self.D), lr=lr)                      # :44
 
+    def double_(self) -> "RefVAEGAN":
+        """Switch the whole model + optimiser state to float64 (call before the first step).  Used by the
+        parity tests to measure how ill-conditioned a quantity is: |cpu-fp32 - fp64| calibrates the tolerance
+        a faithful fp32 implementation can be held to (the trajectory is chaotic)."""
+        assert self.opt_E.t == 0
+        for st in (self.E, self.G, self.D):
+            for k in list(st.keys()):
+                if st[k].is_floating_point():
+                    st[k] = st[k].detach().double()
+        lr = self.opt_E.lr
+        self.opt_E = RefAdam(require_grads(self.E), lr=lr)
+        self.opt_G = RefAdam(require_grads(self.G), lr=lr)
+        self.opt_D = RefAdam(require_grads(self.D), lr=lr)
+        self.dtype = torch.float64
+        return self
+
     def train_step(self, real, eps_z, eps_real, eps_recon, epoch: int,
                    alpha_kl: float = 0.1, alpha_adv: float = 0.1) -> Dict[str, float]:
         """One iteration of vaegan_code.py:65-135; the three randn_like draws are injected."""
         B = real.size(0)
+        dt = getattr(self, "dtype", torch.float32)
+        real, eps_z, eps_real, eps_recon = (t.to(dt) for t in (real, eps_z, eps_real, eps_recon))
         mu, logvar = encoder_forward(self.E, real, True)                        # :74
         logvar = torch.clamp(logvar, min=-10, max=10)                           # :75
         std = torch.exp(0.5 * logvar)                                           # :76
         z = (mu + std * eps_z).unsqueeze(-1).unsqueeze(-1)                      # :77-78
         recon = generator_forward(self.G, self.g_spec, z, True)                # :83
-        real_labels = torch.full((B,), 0.9)                                     # :88
-        fake_labels = torch.full((B,), 0.1)                                     # :89
+        real_labels = torch.full((B,), 0.9, dtype=dt)                           # :88
+        fake_labels = torch.full((B,), 0.1, dtype=dt)                           # :89
         real_noisy = real + 0.05 * eps_real                                     # :91
         recon_noisy = recon + 0.05 * eps_recon                                  # :92
         d_losses = []

@@ -1,0 +1,145 @@
+"""CPU: host-side logic of the product -- module tree / state_dict / init parity with the reference
+(through the golden vectors), loud failure off-GPU, and the C ABI: the shared library loads and
+exports every symbol include/vaegan_hip.h declares (no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import vaegan_ref as R
+from _inputs import tstats
+
+import vaegan_amd as V
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# Encoder.__init__ (main_vae.py:43-45) pushes zeros through the CNN on the CPU.  In exact arithmetic every
+# block then sees zeros (BatchNorm of a constant map is beta = 0); the reference's ATen kernels leave ~1e-6
+# rounding noise instead, so its deeper running_mean buffers are 0.1*bias + O(1e-7).  The product has no CPU
+# compute path and sets the noise-free values; tolerance on exactly these buffers (decays 0.9x per train step).
+_NOISY = re.compile(r"cnn\.[123]\.bn\.running_mean")
+_NOISE_ATOL = 2e-7
+
+
+def _build(S=256):
+    V.configure_seed(42)
+    e = V.Encoder([3, S, S], 100)
+    g = V.Generator(nz=100, img_size=S)
+    d = V.Discriminator(img_size=S)
+    g.apply(V.weights_init)
+    d.apply(V.weights_init)
+    return e, g, d
+
+
+def test_seed42_construction_matches_reference_golden(golden_dir):
+    """vaegan_code.py:19-40: same RNG consumption order, same values, same state_dict keys (App. A.3)."""
+    gold = np.load(os.path.join(golden_dir, "init_seed42.npz"))
+    e, g, d = _build(256)
+    fz = torch.randn(64, 100, 1, 1)
+    np.testing.assert_array_equal(fz.flatten()[:8].numpy(), gold["fixed_noise#samp"])
+    for name, m in (("E", e), ("G", g), ("D", d)):
+        sd = m.state_dict()
+        gold_keys = sorted(k[len(name) + 1:-6] for k in gold.files if k.startswith(name + ".") and k.endswith("#stats"))
+        assert sorted(sd.keys()) == gold_keys
+        for k, v in sd.items():
+            s, samp = tstats(v.float())
+            if _NOISY.search(k):
+                np.testing.assert_allclose(samp, gold[f"{name}.{k}#samp"], rtol=0, atol=_NOISE_ATOL, err_msg=k)
+                continue
+            np.testing.assert_array_equal(s, gold[f"{name}.{k}#stats"], err_msg=f"{name}.{k}")
+            np.testing.assert_array_equal(samp, gold[f"{name}.{k}#samp"], err_msg=f"{name}.{k}")
+
+
+@pytest.mark.parametrize("S", [64, 128, 256])
+def test_encoder_dummy_forward_side_effect_is_reproduced(golden_dir, S):
+    """main_vae.py:43-45 / SURVEY A.2 -- reproduced analytically (no CPU compute path exists)."""
+    gold = np.load(os.path.join(golden_dir, "init_seed42.npz"))
+    V.configure_seed(42)
+    e = V.Encoder([3, S, S], 100)
+    assert e.flatten_size == int(gold[f"E{S}.flatten_size"][0])
+    for i in range(4):
+        np.testing.assert_array_equal(e.cnn[i].conv.bias.detach().numpy(), gold[f"E{S}.cnn.{i}.conv.bias"])
+        if i == 0:
+            np.testing.assert_array_equal(e.cnn[i].bn.running_mean.numpy(), gold[f"E{S}.cnn.{i}.bn.running_mean"])
+        else:
+            np.testing.assert_allclose(e.cnn[i].bn.running_mean.numpy(), gold[f"E{S}.cnn.{i}.bn.running_mean"],
+                                       rtol=0, atol=_NOISE_ATOL)
+        np.testing.assert_array_equal(e.cnn[i].bn.running_var.numpy(), gold[f"E{S}.cnn.{i}.bn.running_var"])
+        assert int(e.cnn[i].bn.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("S", [64, 128, 256])
+def test_state_dict_matches_oracle_family(S):
+    e, g, d = _build(S)
+    o = R.RefVAEGAN(img_size=S, seed=42)
+    for m, st in ((e, o.E), (g, o.G), (d, o.D)):
+        sd = m.state_dict()
+        assert list(sd.keys()) == list(st.keys())
+        for k in sd:
+            if _NOISY.search(k):
+                torch.testing.assert_close(sd[k], st[k].detach(), rtol=0, atol=_NOISE_ATOL)
+            else:
+                assert torch.equal(sd[k], st[k].detach()), k
+
+
+def test_weights_init_matches_on_class_names():
+    g = V.Generator(nz=100, img_size=64)
+    names = {type(m).__name__ for m in g.modules()}
+    assert {"ConvTranspose2d", "BatchNorm2d", "ReLU", "Tanh"} <= names
+    d = V.Discriminator(img_size=64)
+    assert {type(m).__name__ for m in d.main} == {"Conv2d", "BatchNorm2d", "LeakyReLU", "Sigmoid"}
+
+
+def test_no_cpu_fallback():
+    e, g, d = _build(64)
+    with pytest.raises(RuntimeError, match="only runs on the MI355X"):
+        e(torch.zeros(2, 3, 64, 64))
+    with pytest.raises(RuntimeError, match="only runs on the MI355X"):
+        g(torch.zeros(2, 100, 1, 1))
+    with pytest.raises(RuntimeError, match="only runs on the MI355X"):
+        d(torch.zeros(2, 3, 64, 64))
+    with pytest.raises(RuntimeError, match="parameter container"):
+        g.main[0](torch.zeros(2, 100, 1, 1))
+    with pytest.raises(RuntimeError, match="MI355X"):
+        V.Adam(e.parameters(), lr=2e-4)
+
+
+def test_size_rule_rejects_unsupported_sizes():
+    with pytest.raises(ValueError):
+        V.Generator(nz=100, img_size=96)
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "vaegan_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(vg_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_c_abi_library_exports_every_declared_symbol():
+    from importlib import import_module
+    L = import_module("vae-gan-based-model-for-image-generation-and-denoising_amd._lib")
+    assert os.path.isfile(L.LIB_PATH), "libvaegan_hip.so missing: run __graft_entry__.build()"
+    lib = ctypes.CDLL(L.LIB_PATH)
+    declared = _header_functions()
+    assert declared, "no declarations parsed from include/vaegan_hip.h"
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in vaegan_hip.h but not exported"
+    assert sorted(L.SIGNATURES) == declared, "ctypes binding table out of sync with the header"
+    lib.vg_abi_version.restype = ctypes.c_int
+    assert lib.vg_abi_version() == L.ABI_VERSION
+
+
+def test_c_abi_rejects_bad_arguments_on_host():
+    """Shape / alignment validation happens before any launch, so it is testable without a GPU."""
+    from importlib import import_module
+    L = import_module("vae-gan-based-model-for-image-generation-and-denoising_amd._lib")
+    lib = L.load()
+    d = L.GGDesc()                                  # all zeros: NULL pointers, zero sizes
+    assert lib.vg_gather_gemm(ctypes.byref(d), 0, None) == -1
+    assert lib.vg_gather_gemm(ctypes.byref(d), 7, None) == -3
+    w = L.WGDesc()
+    assert lib.vg_wgrad_ws_bytes(ctypes.byref(w), 0) == -1
+    assert lib.vg_adam_step(None, None, None, None, 0, 1e-3, 0.9, 0.999, 1e-8, 1.0, None, None) == -1

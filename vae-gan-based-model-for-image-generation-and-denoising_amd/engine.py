@@ -1,0 +1,274 @@
+"""Network-level sequencing of the HIP kernels: forward and backward of the Encoder, Generator
+and Discriminator stacks (main_vae.py:34-58, gan_code.py:16-89) as explicit kernel chains.
+
+No autograd and no ATen compute in here: every stage is
+    gather-GEMM (conv / convT / linear, + bias, + BN batch statistics in the epilogue)
+ -> bn_finalize (mean / invstd / scale / shift, running-stat update)
+ -> fused scale-shift-activation
+and the backward chain mirrors it (BN+activation backward in two passes, weight gradient,
+data gradient).  Activations live in NHWC; parameters stay in the
+reference's fp32 layouts inside the nn.Modules and are re-packed into K-major GEMM operands
+whenever they change.
+
+The nn.Module classes in nets.py wrap these chains in torch.autograd.Function objects (drop-in
+path); trainer.py drives them directly (fast path, no autograd graph).
+"""
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional
+
+import torch
+
+from . import geometry as G
+from . import ops
+from ._lib import VG_ACT_LRELU, VG_ACT_NONE, VG_ACT_RELU
+
+BN_MOMENTUM, BN_EPS = 0.1, 1e-5       # nn.BatchNorm2d defaults (main_vae.py:24, gan_code.py:22)
+
+# bumped by every optimizer step (optim.Adam.step); packed operand copies older than this are stale
+_weights_epoch = [0]
+
+
+def bump_weights_epoch() -> None:
+    _weights_epoch[0] += 1
+
+
+@dataclass
+class Stage:
+    kind: str                       # 'conv' | 'convT' | 'linear2' | 'head'
+    cin: int
+    cout: int
+    k: int
+    s: int
+    p: int
+    hin: int                        # input spatial size (square)
+    hout: int
+    conv: object = None             # module(s) owning weight / bias
+    conv2: object = None            # second Linear of the fused fc_mu|fc_logvar pair
+    bn: object = None
+    act: int = VG_ACT_NONE
+    slope: float = 0.0
+
+    @property
+    def has_bias(self) -> bool:
+        return getattr(self.conv, "bias", None) is not None
+
+
+class GradSink:
+    """Where parameter gradients go.  direct=True: into param.grad (allocated or accumulated in
+    place -- trainer path); direct=False: fresh tensors collected for autograd to return."""
+
+    def __init__(self, direct: bool):
+        self.direct = direct
+        self.out: Dict[int, torch.Tensor] = {}
+
+    def get(self, param: torch.Tensor):
+        """-> (tensor to write, accumulate flag)"""
+        if not self.direct:
+            t = torch.empty_like(param)
+            self.out[id(param)] = t
+            return t, False
+        if param.grad is None:
+            param.grad = torch.empty_like(param)
+            param._vg_fresh = False
+            return param.grad, False
+        fresh = getattr(param, "_vg_fresh", False)
+        param._vg_fresh = False
+        return param.grad, not fresh
+
+
+class StackEngine:
+    """A chain of conv-like stages sharing one activation dtype."""
+
+    def __init__(self, stages: List[Stage], dtype: int, in_ch: int):
+        self.stages = stages
+        self.dtype = dtype
+        self.in_ch = in_ch
+        self._specs: Dict = {}
+        self._packs: Optional[Dict] = None
+        self._pack_key = None
+        self.pending_bn_ticks = 0           # num_batches_tracked increments not yet applied (flushed lazily)
+
+    # ---- geometry (cached per batch size) -----------------------------------------------------
+    def spec(self, i: int, B: int, what: str):
+        key = (i, B, what)
+        sp = self._specs.get(key)
+        if sp is None:
+            st, dt = self.stages[i], self.dtype
+            a = (B, st.hin, st.hin, st.cin, st.cout, st.k, st.s, st.p, dt)
+            if st.kind == "conv":
+                sp = {"fprop": G.conv_fprop, "dgrad": G.conv_dgrad, "wgrad": G.conv_wgrad}[what](*a)
+            elif st.kind == "convT":
+                sp = {"fprop": G.convT_fprop, "dgrad": G.convT_dgrad, "wgrad": G.convT_wgrad}[what](*a)
+            elif st.kind == "linear2":
+                b = (B, st.hin, st.hin, st.cin, st.cout, dt)
+                sp = {"fprop": G.linear_fprop, "dgrad": G.linear_dgrad, "wgrad": G.linear_wgrad}[what](*b)
+            elif st.kind == "head":
+                sp = G.conv_fprop(*a)
+            self._specs[key] = sp
+        return sp
+
+    # ---- parameter handling ---------------------------------------------------------------------
+    def params(self) -> List[torch.Tensor]:
+        ps = []
+        for st in self.stages:
+            for m in (st.conv, st.conv2):
+                if m is not None:
+                    ps.append(m.weight)
+                    if getattr(m, "bias", None) is not None:
+                        ps.append(m.bias)
+            if st.bn is not None:
+                ps += [st.bn.weight, st.bn.bias]
+        return ps
+
+    def invalidate(self) -> None:
+        self._pack_key = None
+
+    def _ensure_packed(self) -> Dict:
+        key = (_weights_epoch[0], tuple(p._version for p in self.params()), self.stages[0].conv.weight.data_ptr())
+        if self._packs is not None and key == self._pack_key:
+            return self._packs
+        packs = self._packs if self._packs is not None else {}
+        for i, st in enumerate(self.stages):
+            ent = packs.setdefault(i, {})
+            if st.kind == "linear2":
+                w = torch.cat([st.conv.weight.detach(), st.conv2.weight.detach()], 0)
+                ent["wcat"] = w
+                ent["bias"] = torch.cat([st.conv.bias.detach(), st.conv2.bias.detach()], 0)
+            else:
+                w = st.conv.weight.detach()
+                ent["bias"] = st.conv.bias.detach() if st.has_bias else None
+            _, pk = self.spec(i, 1, "fprop") if st.kind != "head" else self.spec(i, 1, "fprop")
+            ent["fprop"] = ops.pack_weights(pk, w, self.dtype, out=ent.get("fprop"))
+            if st.kind != "head":
+                _, pkd = self.spec(i, 1, "dgrad")
+                ent["dgrad"] = ops.pack_weights(pkd, w, self.dtype, out=ent.get("dgrad"))
+        self._packs, self._pack_key = packs, key
+        return packs
+
+    def flush_bn_ticks(self) -> None:
+        if self.pending_bn_ticks:
+            for st in self.stages:
+                if st.bn is not None:
+                    st.bn.num_batches_tracked += self.pending_bn_ticks
+            self.pending_bn_ticks = 0
+
+    # ---- forward ----------------------------------------------------------------------------------
+    def forward(self, x: torch.Tensor, B: int, train: bool, keep: bool = True):
+        """x: NHWC activation of the first stage.  Returns (output, ctx).  For a 'head' last stage the
+        output is p [B] (f32); otherwise the (activated) NHWC output of the last stage."""
+        packs = self._ensure_packed()
+        dt = self.dtype
+        ctx = []
+        a = x
+        for i, st in enumerate(self.stages):
+            if st.kind == "head":
+                K = st.hin * st.hin * G.padc(st.cin, dt)
+                p = ops.dot_sigmoid_forward(a, packs[i]["fprop"], B, K, dt)
+                ctx.append({"x": a, "p": p})
+                a = p
+                continue
+            gg, pk = self.spec(i, B, "fprop")
+            want_stats = st.bn is not None and train
+            # the "taps folded into N" GEMM has one column per (tap, channel): its epilogue sums are not
+            # per-channel, so that (tiny) stage takes its BatchNorm statistics from a separate pass
+            epilogue_stats = want_stats and not pk.tap_in_n
+            Y, stats, nparts = ops.gather_gemm(gg, a, packs[i]["fprop"], dt, bias=packs[i]["bias"],
+                                               want_stats=epilogue_stats)
+            OC = G.padc(st.cout, dt)
+            Y = Y.view(B, st.hout, st.hout, OC)
+            rows = B * st.hout * st.hout
+            if want_stats and not epilogue_stats:
+                stats, nparts = ops.channel_stats(Y, rows, OC, dt)
+            coeffs = None
+            if st.bn is not None:
+                bn = st.bn
+                if train:
+                    coeffs = ops.bn_finalize(stats, nparts, st.cout, rows, bn.weight.detach(), bn.bias.detach(),
+                                             bn.running_mean, bn.running_var, BN_MOMENTUM, BN_EPS, Y.device)
+                else:
+                    coeffs = ops.bn_eval_coeffs(bn.weight.detach(), bn.bias.detach(), bn.running_mean,
+                                                bn.running_var, BN_EPS)
+                out = ops.bn_act_forward(Y, coeffs, rows, OC, st.act, st.slope, dt)
+            elif st.act != VG_ACT_NONE:
+                out = ops.bn_act_forward(Y, None, rows, OC, st.act, st.slope, dt)
+            else:
+                out = Y
+            if keep:
+                ctx.append({"x": a, "Y": Y, "coeffs": coeffs, "rows": rows, "OC": OC})
+            a = out
+        if train and any(st.bn is not None for st in self.stages):
+            self.pending_bn_ticks += 1
+        return a, (ctx, B, train)
+
+    # ---- backward ---------------------------------------------------------------------------------
+    def backward(self, ctxpack, dout: torch.Tensor, need_dx: bool, sink: GradSink, param_grads: bool = True):
+        """dout: gradient w.r.t. forward()'s output.  Returns the gradient w.r.t. the NHWC input (or None).
+        param_grads=False skips every weight/bias/BN-parameter gradient (legal when the caller discards
+        them, e.g. the generator-loss pass through the discriminator)."""
+        ctx, B, train = ctxpack
+        if not train:
+            raise RuntimeError("backward through an eval-mode network is not supported (the reference never does it)")
+        packs = self._ensure_packed()
+        dt = self.dtype
+        dA = dout
+        for i in range(len(self.stages) - 1, -1, -1):
+            st, c = self.stages[i], ctx[i]
+            want_dx = need_dx or i > 0
+            if st.kind == "head":
+                K = st.hin * st.hin * G.padc(st.cin, dt)
+                dx, dlogit = ops.dot_sigmoid_backward(c["p"], dA, packs[i]["fprop"], B, K, dt, want_dx, c["x"])
+                if param_grads:
+                    gw, acc = sink.get(st.conv.weight)
+                    ops.dot_wgrad(c["x"], dlogit, gw, B, K, G.padc(st.cin, dt), st.hin * st.hin, acc, dt)
+                dA = dx
+                continue
+            Y, rows, OC = c["Y"], c["rows"], c["OC"]
+            dA = dA.view(Y.shape) if dA.shape != Y.shape else dA
+            if st.bn is not None:
+                if param_grads:
+                    gg_, acc_g = sink.get(st.bn.weight)
+                    gb_, acc_b = sink.get(st.bn.bias)
+                    assert acc_g == acc_b
+                else:
+                    gg_, gb_, acc_g = None, None, False
+                dY = ops.bn_act_backward(Y, dA, c["coeffs"], rows, OC, rows, st.bn.weight.detach(), st.act, st.slope,
+                                         gg_, gb_, acc_g, dt)
+            elif st.act != VG_ACT_NONE:
+                dY = ops.act_backward(Y, dA, st.act, st.slope, dt)
+            else:
+                dY = dA
+            if param_grads:
+                self._param_grads(i, st, c, dY, B, rows, OC, sink)
+            if want_dx:
+                ggd, _ = self.spec(i, B, "dgrad")
+                dX, _, _ = ops.gather_gemm(ggd, dY, packs[i]["dgrad"], dt)
+                dA = dX.view(c["x"].shape)
+            else:
+                dA = None
+        return dA
+
+    def _param_grads(self, i, st, c, dY, B, rows, OC, sink):
+        dt = self.dtype
+        wg = self.spec(i, B, "wgrad")
+        if st.kind == "linear2":
+            N1 = st.conv.weight.shape[0]
+            tmp = torch.empty(st.cout, st.conv.weight.shape[1], dtype=torch.float32, device=dY.device)
+            ops.wgrad(wg, dY, c["x"], tmp, False, dt)
+            tb = torch.empty(st.cout, dtype=torch.float32, device=dY.device)
+            ops.bias_grad(dY, rows, OC, st.cout, tb, False, dt)
+            for m, sl in ((st.conv, slice(0, N1)), (st.conv2, slice(N1, st.cout))):
+                for prm, src in ((m.weight, tmp[sl]), (m.bias, tb[sl])):
+                    g, acc = sink.get(prm)
+                    if acc:
+                        ops.axpy(g, src.contiguous(), 1.0, out=g)
+                    else:
+                        g.copy_(src)
+            return
+        gw, acc = sink.get(st.conv.weight)
+        if st.kind == "conv":
+            ops.wgrad(wg, dY, c["x"], gw, acc, dt)
+        else:
+            ops.wgrad(wg, c["x"], dY, gw, acc, dt)
+        if st.has_bias:
+            gb, accb = sink.get(st.conv.bias)
+            ops.bias_grad(dY, rows, OC, st.cout, gb, accb, dt)

@@ -1,0 +1,121 @@
+"""The VAE-GAN training iteration of the reference (vaegan_code.py:65-135) driven directly on the
+HIP kernel chains -- no autograd graph, gradients written straight into the optimizers' flat
+buffers.  Same op order, loss weights, zero_grad/step order and BatchNorm modes as the reference
+(SURVEY.md A13); the three ``randn_like`` draws (vaegan_code.py:77,91,92) can be injected for
+parity runs or are drawn on the device.
+
+    trainer = VAEGANTrainer(encoder, decoder, discriminator, opt_E, opt_Dec, opt_Dis)
+    losses = trainer.train_step(real_images, epoch)          # device tensor, no host sync
+"""
+from typing import Dict, Optional
+
+import torch
+
+from . import geometry as G
+from . import ops
+from .engine import GradSink
+
+LOSS_NAMES = ("recon_loss", "kl_loss", "g_loss_adv", "d_loss_1", "d_loss_2")
+
+
+class VAEGANTrainer:
+    def __init__(self, encoder, decoder, discriminator, opt_E, opt_Dec, opt_Dis, alpha_kl: float = 0.1,
+                 alpha_adv: float = 0.1, noise_sigma: float = 0.05, real_label: float = 0.9, fake_label: float = 0.1,
+                 d_iters: int = 2, elide_dead_grads: bool = False, reducer=None):
+        self.E, self.G, self.D = encoder, decoder, discriminator
+        self.opt_E, self.opt_G, self.opt_D = opt_E, opt_Dec, opt_Dis
+        self.alpha_kl, self.alpha_adv, self.sigma = alpha_kl, alpha_adv, noise_sigma          # :49-50, :91-92
+        self.real_label, self.fake_label, self.d_iters = real_label, fake_label, d_iters      # :88-89, :95
+        # The generator-loss pass through D (vaegan_code.py:110,133) also produces D weight gradients that the
+        # next opt_Dis.zero_grad() discards unread.  False = compute them anyway (what the reference executes).
+        self.elide_dead_grads = elide_dead_grads
+        self.reducer = reducer
+        dts = {encoder._dt, decoder._dt, discriminator._dt}
+        if len(dts) != 1:
+            raise ValueError("encoder / decoder / discriminator must share one engine dtype")
+        self.dt = dts.pop()
+        self.latent = encoder.latent_dim
+        self.losses = None
+
+    def train(self):
+        self.E.train(), self.G.train(), self.D.train()                                         # :56-58
+
+    def train_step(self, real: torch.Tensor, epoch: int, eps_z: Optional[torch.Tensor] = None,
+                   eps_real: Optional[torch.Tensor] = None, eps_recon: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """One iteration.  Returns a device tensor [recon_loss, kl_loss, g_loss_adv, d_loss_1, d_loss_2]."""
+        if not real.is_cuda:
+            raise RuntimeError("train_step needs the batch on the MI355X ('cuda'); there is no CPU path")
+        E, Gn, D, dt = self.E, self.G, self.D, self.dt
+        B, dev = real.shape[0], real.device
+        L = self.latent
+        real = real.contiguous()
+        if eps_z is None:
+            eps_z = torch.randn(B, L, device=dev)                                             # :77
+        if eps_real is None:
+            eps_real = torch.randn_like(real)                                                 # :91
+        if eps_recon is None:
+            eps_recon = torch.randn_like(real)                                                # :92
+        losses = torch.zeros(8, dtype=torch.float32, device=dev)
+        sink = GradSink(direct=True)
+
+        # ---- Encode / reparameterise / decode (:74-83) ----
+        mulv, ctxE = E.engine_forward(real)
+        ZP = G.padc(Gn.nz, dt)
+        z, lvc = ops.reparam_forward(mulv, eps_z, L, ZP, dt)
+        pre, ctxG = Gn.engine_forward(z, B)
+        recon = ops.nhwc_to_nchw(pre, Gn.nc, dt, apply_tanh=True)
+
+        # ---- instance noise, drawn once per step (:91-92); produced directly in the layout D reads ----
+        CP = G.padc(D.nc, dt)
+        real_noisy = ops.nchw_to_nhwc(real, CP, dt, eps=eps_real, sigma=self.sigma)
+        recon_noisy = ops.nchw_to_nhwc(recon, CP, dt, eps=eps_recon, sigma=self.sigma)
+
+        # ---- Discriminator updates (:95-105) ----
+        for it in range(self.d_iters):
+            p_real, c_real = D.engine_forward(real_noisy, B)
+            p_fake, c_fake = D.engine_forward(recon_noisy, B)                                  # .detach(): no dx below
+            slot = losses[3 + min(it, 1):4 + min(it, 1)]
+            dp_real = ops.bce_forward_backward(p_real, self.real_label, 1.0, slot, False, True)
+            dp_fake = ops.bce_forward_backward(p_fake, self.fake_label, 1.0, slot, True, True)
+            self.opt_D.zero_grad(memset=False)
+            D._engine.backward(c_real, dp_real, False, sink)
+            D._engine.backward(c_fake, dp_fake, False, sink)
+            if self.reducer is not None:
+                self.reducer.reduce(self.opt_D)
+            self.opt_D.step()
+
+        # ---- Generator + VAE loss (:110-117) ----
+        p_adv, c_adv = D.engine_forward(recon_noisy, B)
+        d_recon = ops.mse_forward_backward(recon, real, 1.0, losses[0:1], True)               # :113
+        ops.kl_forward(mulv, lvc, L, float(B), dt, out=losses[1:2])                           # :114
+        dp_adv = ops.bce_forward_backward(p_adv, self.real_label, self.alpha_adv, losses[2:3], False, True)  # :115
+
+        # ---- backward of total = recon + a_kl*min(1,epoch/50)*kl + a_adv*adv, then E and G steps (:131-135) ----
+        self.opt_E.zero_grad(memset=False)
+        self.opt_G.zero_grad(memset=False)
+        d_noisy = D._engine.backward(c_adv, dp_adv, True, sink, param_grads=not self.elide_dead_grads)
+        d_img = ops.nhwc_to_nchw(d_noisy, Gn.nc, dt)
+        ops.axpy(d_recon, d_img, 1.0, out=d_recon)
+        d_pre = ops.nchw_grad_to_nhwc(d_recon, recon, G.padc(Gn.nc, dt), dt)
+        dz = Gn._engine.backward(ctxG, d_pre, True, sink)
+        if self.reducer is not None:
+            self.reducer.reduce_async(self.opt_G)                  # overlaps with the encoder's backward
+        kl_w = self.alpha_kl * min(1.0, epoch / 50)                                            # :117
+        dmulv = ops.reparam_kl_backward(mulv, lvc, eps_z, dz, kl_w / B, L, dt)
+        E._engine.backward(ctxE, dmulv.view(B, 1, 1, -1), False, sink)
+        if self.reducer is not None:
+            self.reducer.reduce(self.opt_E)
+            self.reducer.wait(self.opt_G)
+        self.opt_E.step()
+        self.opt_G.step()
+        self.losses = losses
+        return losses
+
+    def loss_dict(self, losses: Optional[torch.Tensor] = None, epoch: Optional[int] = None) -> Dict[str, float]:
+        """Host copy of the last step's losses (one device sync, like the reference's .item() calls :125-127)."""
+        v = (losses if losses is not None else self.losses)[:5].tolist()
+        out = dict(zip(LOSS_NAMES, v))
+        if epoch is not None:
+            out["total"] = out["recon_loss"] + self.alpha_kl * min(1.0, epoch / 50) * out["kl_loss"] \
+                + self.alpha_adv * out["g_loss_adv"]
+        return out
