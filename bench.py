@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""Benchmark of the VAE-GAN training iteration (vaegan_code.py:65-135) on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one full iteration: E fwd, G fwd, 5 D fwd, all backward passes, 4 Adam steps (+ gradient
+all-reduces over RCCL when N > 1).  Workload (BASELINE.json configs[1], SURVEY.md 8(d) "C2"): CelebA-shaped
+synthetic 64x64 images, batch 128 PER GPU (weak scaling), inputs (images and the three noise tensors) resident
+in HBM before the timed region, seed-42 random-init weights of the A0 size family.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+# ALGORITHMIC conv/convT/linear FLOP per image per step (fwd + wgrad + dgrad, D x5)
+ALG_GFLOP_PER_IMAGE = {64: 6.45, 128: 8.77, 256: 12.561}
+PEAK = {"fp32": 157.3, "bf16": 2500.0}          # dense MFMA TFLOP/s, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def make_inputs(B, S, seed, latent=100):
+    g = torch.Generator().manual_seed(seed)
+    real = torch.rand(B, 3, S, S, generator=g) * 2 - 1
+    return real, torch.randn(B, latent, generator=g), torch.randn(B, 3, S, S, generator=g), \
+        torch.randn(B, 3, S, S, generator=g)
+
+
+def cpu_baseline(S, B, budget_s=25.0):
+    """The CPU oracle (bit-checked against the reference classes, tests/golden) timed on this box's host cores:
+    a bounded sample of the same workload.  Reported baseline only."""
+    import vaegan_ref as R
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 32))
+    torch.set_num_threads(cores)
+    o = R.RefVAEGAN(img_size=S, seed=42)
+    inp = make_inputs(B, S, 1234)
+    t0 = time.time()
+    o.train_step(*inp, 60)                                   # warm-up (also sizes the sample)
+    warm = time.time() - t0
+    steps = max(1, min(5, int(budget_s / max(warm, 1e-3))))
+    t0 = time.time()
+    for _ in range(steps):
+        o.train_step(*inp, 60)
+    dt = (time.time() - t0) / steps
+    return {"value": round(B / dt, 2), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} full training steps of S={S} B={B} fp32 after 1 warm-up, CPU oracle "
+                      f"(oracle/vaegan_ref.py, same ATen CPU kernels the reference executes)",
+            "s_per_step": round(dt, 3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--size", type=int, default=64)
+    ap.add_argument("--batch", type=int, default=128, help="per-GPU batch")
+    ap.add_argument("--dtype", default=os.environ.get("VAEGAN_BENCH_DTYPE", "fp32"), choices=["fp32", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--elide-dead-grads", action="store_true",
+                    help="skip the D weight gradients of the generator-loss pass that the reference computes and discards")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with torch.distributed.run for --gpus > 1 (see module docstring)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import vaegan_amd as V
+    from importlib import import_module
+    ops = import_module("vae-gan-based-model-for-image-generation-and-denoising_amd.ops")
+    ddp = import_module("vae-gan-based-model-for-image-generation-and-denoising_amd.ddp")
+
+    S, B = args.size, args.batch
+    V.configure_seed(42)
+    e = V.Encoder([3, S, S], 100, dtype=args.dtype)
+    g = V.Generator(nz=100, img_size=S, dtype=args.dtype)
+    d = V.Discriminator(img_size=S, dtype=args.dtype)
+    g.apply(V.weights_init), d.apply(V.weights_init)
+    e.to(dev), g.to(dev), d.to(dev)
+    oE, oG, oD = (V.Adam(m.parameters(), lr=2e-4) for m in (e, g, d))
+    reducer = None
+    if world > 1:
+        reducer = ddp.GradReducer()
+        reducer.attach(oE, oG, oD)
+        reducer.broadcast_parameters(oE, oG, oD)
+    tr = V.VAEGANTrainer(e, g, d, oE, oG, oD, elide_dead_grads=args.elide_dead_grads, reducer=reducer)
+    tr.train()
+    real, ez, er, ec = (t.to(dev) for t in make_inputs(B, S, 1234 + rank))
+    epoch = 60
+
+    for _ in range(args.warmup):
+        tr.train_step(real, epoch, ez, er, ec)
+    timer = ops.KernelTimer() if rank == 0 else None
+    ops.set_timer(timer)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = tr.train_step(real, epoch, ez, er, ec)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ops.set_timer(None)
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ms = elapsed / args.steps * 1e3
+    value = world * B * args.steps / elapsed
+    ld = tr.loss_dict(losses, epoch)
+    assert all(v == v and abs(v) < 1e6 for v in ld.values()), f"non-finite losses: {ld}"
+
+    # ---- roofline of the dominant kernel family (implicit-GEMM conv fprop+dgrad), measured live ----
+    fam = timer.summary()
+    gg = fam.get("gather_gemm", dict(launches=0, ms=1e-9, flops=0, bytes=0))
+    wg = fam.get("wgrad", dict(launches=0, ms=1e-9, flops=0, bytes=0))
+    ach = gg["flops"] / (gg["ms"] * 1e-3) / 1e12
+    roofline = {"bound": "mfma", "kernel": "gg_kernel (gather-GEMM: conv/convT/linear fprop + dgrad)",
+                "achieved": round(ach, 2), "peak": PEAK[args.dtype], "unit": "TFLOP/s",
+                "frac": round(ach / PEAK[args.dtype], 4), "traffic": None,
+                "launches_per_step": gg["launches"] // args.steps,
+                "avg_launch_us": round(gg["ms"] * 1e3 / max(gg["launches"], 1), 2),
+                "alg_gflop_per_launch": round(gg["flops"] / max(gg["launches"], 1) / 1e9, 3),
+                "share_of_step": round(gg["ms"] / (elapsed * 1e3), 3),
+                "alg_bytes_gbs": round(gg["bytes"] / (gg["ms"] * 1e-3) / 1e9, 1),
+                "wgrad": {"achieved": round(wg["flops"] / (wg["ms"] * 1e-3) / 1e12, 2),
+                          "launches_per_step": wg["launches"] // args.steps,
+                          "share_of_step": round(wg["ms"] / (elapsed * 1e3), 3)},
+                "step_alg_tflops": round(ALG_GFLOP_PER_IMAGE.get(S, 0) * B / ms, 2)}
+    out = {"metric": "images/sec/GPU VAE-GAN train step", "value": round(value, 1), "unit": "images/sec",
+           "per_gpu": round(value / world, 1), "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": {"fp32": "f32", "bf16": "bf16"}[args.dtype], "data": "synthetic",
+           "config": {"workload": f"CelebA-shaped {S}x{S} VAE-GAN full train step (E+G+5xD fwd, all bwd, 4 Adam), "
+                                  f"batch {B}/GPU, global batch {B * world}", "img_size": S, "per_gpu_batch": B,
+                      "global_batch": B * world, "parallelism": f"dp{world}", "epoch_kl_weight": 0.1,
+                      "elide_dead_grads": bool(args.elide_dead_grads)},
+           "losses": {k: round(v, 5) for k, v in ld.items()},
+           "roofline": roofline}
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(S, B)
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -52,6 +52,21 @@ class Stage:
     def has_bias(self) -> bool:
         return getattr(self.conv, "bias", None) is not None
 
+    def alg(self, B: int, dtype: int):
+        """ALGORITHMIC work of one pass (fprop, dgrad or wgrad -- all equal) of this layer for a batch of B:
+        FLOP = 2*Cin*Cout*k^2*(Hout^2 | Hin^2 for transposed); bytes = |X| + |Y| + |W|
+        at storage width."""
+        es = G.esize(dtype)
+        if self.kind == "linear2":
+            macs = self.cin * self.hin * self.hin * self.cout
+            wel = macs
+        else:
+            sp = self.hin if self.kind == "convT" else self.hout
+            macs = self.cin * self.cout * self.k * self.k * sp * sp
+            wel = self.cin * self.cout * self.k * self.k
+        nbytes = B * (self.hin * self.hin * self.cin + self.hout * self.hout * self.cout) * es + wel * es
+        return 2 * B * macs, nbytes
+
 
 class GradSink:
     """Where parameter gradients go.  direct=True: into param.grad (allocated or accumulated in
@@ -173,7 +188,7 @@ class StackEngine:
             # per-channel, so that (tiny) stage takes its BatchNorm statistics from a separate pass
             epilogue_stats = want_stats and not pk.tap_in_n
             Y, stats, nparts = ops.gather_gemm(gg, a, packs[i]["fprop"], dt, bias=packs[i]["bias"],
-                                               want_stats=epilogue_stats)
+                                               want_stats=epilogue_stats, alg=st.alg(B, dt))
             OC = G.padc(st.cout, dt)
             Y = Y.view(B, st.hout, st.hout, OC)
             rows = B * st.hout * st.hout
@@ -241,7 +256,7 @@ class StackEngine:
                 self._param_grads(i, st, c, dY, B, rows, OC, sink)
             if want_dx:
                 ggd, _ = self.spec(i, B, "dgrad")
-                dX, _, _ = ops.gather_gemm(ggd, dY, packs[i]["dgrad"], dt)
+                dX, _, _ = ops.gather_gemm(ggd, dY, packs[i]["dgrad"], dt, alg=st.alg(B, dt))
                 dA = dX.view(c["x"].shape)
             else:
                 dA = None
@@ -253,7 +268,7 @@ class StackEngine:
         if st.kind == "linear2":
             N1 = st.conv.weight.shape[0]
             tmp = torch.empty(st.cout, st.conv.weight.shape[1], dtype=torch.float32, device=dY.device)
-            ops.wgrad(wg, dY, c["x"], tmp, False, dt)
+            ops.wgrad(wg, dY, c["x"], tmp, False, dt, alg=st.alg(B, dt))
             tb = torch.empty(st.cout, dtype=torch.float32, device=dY.device)
             ops.bias_grad(dY, rows, OC, st.cout, tb, False, dt)
             for m, sl in ((st.conv, slice(0, N1)), (st.conv2, slice(N1, st.cout))):
@@ -266,9 +281,9 @@ class StackEngine:
             return
         gw, acc = sink.get(st.conv.weight)
         if st.kind == "conv":
-            ops.wgrad(wg, dY, c["x"], gw, acc, dt)
+            ops.wgrad(wg, dY, c["x"], gw, acc, dt, alg=st.alg(B, dt))
         else:
-            ops.wgrad(wg, c["x"], dY, gw, acc, dt)
+            ops.wgrad(wg, c["x"], dY, gw, acc, dt, alg=st.alg(B, dt))
         if st.has_bias:
             gb, accb = sink.get(st.conv.bias)
             ops.bias_grad(dY, rows, OC, st.cout, gb, accb, dt)

@@ -43,6 +43,43 @@ class _Workspace:
 WS = _Workspace()
 
 
+class KernelTimer:
+    """Optional live timing of the GEMM-class launches with HIP events recorded on the launch stream
+    (bench.py's roofline leg).  Off by default: no events are created unless a timer is installed."""
+
+    def __init__(self):
+        self.rec = []          # (family, flops, bytes, ev0, ev1)
+
+    def begin(self, family, flops, nbytes):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        return (family, flops, nbytes, e0, e1)
+
+    def end(self, tok):
+        tok[4].record()
+        self.rec.append(tok)
+
+    def summary(self):
+        """family -> dict(launches, ms, flops, bytes); call after a device synchronise."""
+        out = {}
+        for fam, fl, nb, e0, e1 in self.rec:
+            d = out.setdefault(fam, dict(launches=0, ms=0.0, flops=0, bytes=0))
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += fl
+            d["bytes"] += nb
+        return out
+
+
+TIMER = None
+
+
+def set_timer(t) -> None:
+    global TIMER
+    TIMER = t
+
+
 def empty_act(shape, dtype: int, device) -> torch.Tensor:
     return torch.empty(shape, dtype=TORCH_DT[dtype], device=device)
 
@@ -70,8 +107,8 @@ def _gg_desc(g: GGSpec, X, Wp, Y, bias, stats, cap) -> L.GGDesc:
 
 
 def gather_gemm(g: GGSpec, X: torch.Tensor, Wp: torch.Tensor, dtype: int, bias: torch.Tensor = None,
-                want_stats: bool = False, out: torch.Tensor = None):
-    """Returns (Y [B,OH,OW,OC], stats slabs or None, nparts)."""
+                want_stats: bool = False, out: torch.Tensor = None, alg=None):
+    """Returns (Y [B,OH,OW,OC], stats slabs or None, nparts).  alg = (flops, bytes) of the layer for the timer."""
     _need_cuda(X, Wp, bias, out)
     if X.dtype != TORCH_DT[dtype] or Wp.dtype != TORCH_DT[dtype]:
         raise RuntimeError(f"gather_gemm: operand dtype {X.dtype}/{Wp.dtype} does not match engine dtype")
@@ -92,11 +129,15 @@ def gather_gemm(g: GGSpec, X: torch.Tensor, Wp: torch.Tensor, dtype: int, bias: 
             L.check(nparts, "vg_gather_gemm_nparts")
         stats = WS.get("stats", nparts * 2 * g.N * 4, X.device)
     d = _gg_desc(g, X, Wp, Y, bias, stats, nparts)
+    tok = TIMER.begin("gather_gemm", *(alg or (g.flops(), 0))) if TIMER is not None else None
     L.check(lib.vg_gather_gemm(byref(d), dtype, L.stream_ptr()), "vg_gather_gemm")
+    if tok is not None:
+        TIMER.end(tok)
     return Y, stats, nparts
 
 
-def wgrad(wg: WGSpec, P: torch.Tensor, Q: torch.Tensor, dW: torch.Tensor, accumulate: bool, dtype: int) -> None:
+def wgrad(wg: WGSpec, P: torch.Tensor, Q: torch.Tensor, dW: torch.Tensor, accumulate: bool, dtype: int,
+          alg=None) -> None:
     _need_cuda(P, Q, dW)
     if dW.dtype != torch.float32:
         raise RuntimeError("weight gradients are float32")
@@ -113,7 +154,10 @@ def wgrad(wg: WGSpec, P: torch.Tensor, Q: torch.Tensor, dW: torch.Tensor, accumu
     ws = WS.get("wgrad", nbytes, P.device)
     d.ws = ws.data_ptr()
     d.ws_bytes = ws.numel() * 4
+    tok = TIMER.begin("wgrad", *(alg or (0, 0))) if TIMER is not None else None
     L.check(lib.vg_wgrad(byref(d), dtype, L.stream_ptr()), "vg_wgrad")
+    if tok is not None:
+        TIMER.end(tok)
 
 
 # ---------------------------------------------------------------------------------------------
