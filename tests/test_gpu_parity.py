@@ -181,6 +181,11 @@ def test_teacher_forced_steps_adam_and_batchnorm_state(S, B):
                 elif k.endswith("running_mean") or k.endswith("running_var"):
                     err = float((v.cpu() - r).abs().max() / r.abs().max())
                     assert err <= 2e-3, f"step {step} {k}: running stat differs by {err:.2e} of its max"
+                elif k.endswith("conv.bias"):
+                    # A conv bias in front of BatchNorm has an exactly-zero true gradient: what Adam normalises
+                    # there is pure rounding noise (|g| ~ 1e-8..1e-7 in the reference too) -> +-lr steps of random
+                    # sign in every implementation; only boundedness can be checked.
+                    assert float((v.cpu() - before[k]).abs().max()) <= 1.05 * 2e-4, k
                 else:
                     # One Adam step: |delta| <= ~lr.  Isolated elements whose gradient is rounding noise flip sign
                     # (error up to 2*lr in any fp32 implementation); the bulk must agree.
