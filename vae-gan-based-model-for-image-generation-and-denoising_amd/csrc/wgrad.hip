@@ -147,26 +147,189 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const vg_wg_desc d, int rows
             }
 }
 
-__global__ void wgrad_reduce_kernel(const vg_wg_desc d, int nsplit, int NPpad, int ldk) {
-    // one thread per (np, t, cq) real weight element
+// ---------------------------------------------------------------------------------------------------
+// bf16 variant on v_mfma_f32_16x16x32_bf16.  The reduction index of the MFMA is the pixel index m, which is
+// the STRIDED dimension of both NHWC operands, so fragments are fetched with the gfx950 transposing LDS read
+// (ds_read_b64_tr_b16: a 16-lane group reads a 4-row x 16-column block and receives it column-major).
+//   * 128 x 128 output tile per workgroup (4 waves, 64 x 64 each = 4x4 MFMA tiles), 64 pixel rows per stage,
+//     both operands staged [row][128 cols] exactly as they lie in HBM (8 x 16-byte loads in flight per thread);
+//   * LDS rows are 256 B; the 32-byte column blocks are XOR-swizzled with (row & 7), and MFMA k index
+//     (lane group g, half h, element q) is mapped to row 16h + 4g + q, so the 8 rows one 32-lane half touches
+//     land in 8 different 32-byte bank groups: conflict-free transposed reads (cdna_hip_programming.md T10);
+//     the k permutation is harmless because A and B use the same one;
+//   * the (batch, y, x) decomposition of the 64 rows of a stage is done once by one wave into an LDS table.
+constexpr int WB_T = 128, WB_SM = 64, WB_PITCH = 256;       // tile edge, rows per stage, LDS row bytes
+
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* tile, int krow0, int col0, int lane) {
+    // operand fragment for 16 columns starting at col0, 32 k-rows starting at krow0
+    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const int cb = col0 >> 4;
+    const int r0 = krow0 + 4 * g + q, r1 = r0 + 16;
+    const unsigned char* a0 = tile + r0 * WB_PITCH + ((cb ^ (r0 & 7)) << 5) + 8 * p;
+    const unsigned char* a1 = tile + r1 * WB_PITCH + ((cb ^ (r1 & 7)) << 5) + 8 * p;
+    bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_t*)a0);
+    bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_t*)a1);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__global__ __launch_bounds__(256) void wgrad_bf16_kernel(const vg_wg_desc d, int rows_per_split, int KQ, int NPpad) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][WB_SM * WB_PITCH];   // [buf][P|Q]
+    __shared__ int rowtab[2][WB_SM][3];                                                    // img base, iy0, ix0
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wnp = wave >> 1, wkq = wave & 1;
+    const int kq0 = blockIdx.x * WB_T;
+    const int np0 = blockIdx.y * WB_T;
+    const int M = d.B * d.GH * d.GW;
+    const int GHW = d.GH * d.GW;
+    const int m_begin = blockIdx.z * rows_per_split;
+    const int m_end = min(M, m_begin + rows_per_split);
+
+    const int unit = tid & 15;                     // 16-byte unit (8 bf16) within the 128-column tile row
+    const int urow = tid >> 4;                     // 0..15, rows urow + 16*i
+    const int kq_e = kq0 + unit * 8;
+    const bool q_ok = kq_e < KQ;
+    const int t = q_ok ? kq_e / d.QC : 0;
+    const int cq = kq_e - t * d.QC;
+    const int ta = t / d.TW, tb = t - ta * d.TW;
+    const int qdy = d.DY * ta, qdx = d.DX * tb;
+    const bool p_ok = np0 + unit * 8 < d.PC;
+    const unsigned char* Pb = reinterpret_cast<const unsigned char*>(d.P);
+    const unsigned char* Qb = reinterpret_cast<const unsigned char*>(d.Q);
+
+    auto fill_table = [&](int buf, int ms) {
+        if (tid < WB_SM) {
+            const int m = ms + tid;
+            int base = 0, iy0 = -(1 << 28), ix0 = 0;
+            if (m < m_end) {
+                const int b = m / GHW;
+                const int r = m - b * GHW;
+                const int gy = r / d.GW;
+                const int gx = r - gy * d.GW;
+                base = b * d.QH * d.QW;
+                iy0 = gy * d.SY + d.y0;
+                ix0 = gx * d.SX + d.x0;
+            }
+            rowtab[buf][tid][0] = base;
+            rowtab[buf][tid][1] = iy0;
+            rowtab[buf][tid][2] = ix0;
+        }
+    };
+
+    u32x4 rp[4], rq[4];
+    auto load_stage = [&](int buf, int ms) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = urow + 16 * i;
+            const int m = ms + r;
+            u32x4 vp = {0u, 0u, 0u, 0u}, vq = {0u, 0u, 0u, 0u};
+            if (p_ok && m < m_end) vp = *reinterpret_cast<const u32x4*>(Pb + ((int64_t)m * d.PC + np0 + unit * 8) * 2);
+            const int iy = rowtab[buf][r][1] + qdy, ix = rowtab[buf][r][2] + qdx;
+            if (q_ok && (unsigned)iy < (unsigned)d.QH && (unsigned)ix < (unsigned)d.QW)
+                vq = *reinterpret_cast<const u32x4*>(
+                    Qb + ((int64_t)(rowtab[buf][r][0] + iy * d.QW + ix) * d.QC + cq) * 2);
+            rp[i] = vp;
+            rq[i] = vq;
+        }
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = urow + 16 * i;
+            const int off = r * WB_PITCH + ((((unit >> 1) ^ (r & 7)) << 5) | ((unit & 1) << 4));
+            *reinterpret_cast<u32x4*>(&smem[buf][0][off]) = rp[i];
+            *reinterpret_cast<u32x4*>(&smem[buf][1][off]) = rq[i];
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nstage = (m_end - m_begin + WB_SM - 1) / WB_SM;
+    fill_table(0, m_begin);
+    __syncthreads();
+    if (nstage > 0) {
+        load_stage(0, m_begin);
+        store_stage(0);
+    }
+    if (nstage > 1) fill_table(1, m_begin + WB_SM);
+    __syncthreads();
+    for (int s = 0; s < nstage; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nstage) load_stage(buf ^ 1, m_begin + (s + 1) * WB_SM);        // table[buf^1] filled last iteration
+        const unsigned char* sp = smem[buf][0];
+        const unsigned char* sq = smem[buf][1];
+#pragma unroll
+        for (int ks = 0; ks < WB_SM / 32; ++ks) {
+            bf16x8 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = tr_frag(sp, ks * 32, wnp * 64 + i * 16, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = tr_frag(sq, ks * 32, wkq * 64 + j * 16, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (s + 1 < nstage) store_stage(buf ^ 1);
+        if (s + 2 < nstage) fill_table(buf, m_begin + (s + 2) * WB_SM);            // table[buf] no longer needed
+        __syncthreads();
+    }
+    float* slab = d.ws + (int64_t)blockIdx.z * NPpad * (int64_t)(gridDim.x * WB_T);
+    const int ldk = gridDim.x * WB_T;
+    const int fi = lane & 15, fk = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int np = np0 + wnp * 64 + i * 16 + fk * 4 + r;
+                const int kq = kq0 + wkq * 64 + j * 16 + fi;
+                slab[(int64_t)np * ldk + kq] = acc[i][j][r];
+            }
+}
+
+// Sum the split slabs in fixed order and scatter into the reference parameter layout.  A block is EL output
+// elements x SPL split lanes (EL*SPL = 256): with few output elements and ~1000 slabs a one-thread-per-element
+// loop is a serial chain of ~1000 HBM latencies, so the slabs are walked by SPL lanes and combined through LDS.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const vg_wg_desc d, int nsplit, int NPpad, int ldk, int SPL) {
+    __shared__ float red[256];
+    const int EL = 256 / SPL;
+    const int e = threadIdx.x % EL, sp = threadIdx.x / EL;
     const int T = d.TH * d.TW;
     const int64_t total = (int64_t)d.NP * T * d.NQ;
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const int cqi = (int)(idx % d.NQ);
-    const int64_t r = idx / d.NQ;
-    const int t = (int)(r % T);
-    const int np = (int)(r / T);
-    const int kq = t * d.QC + cqi;
-    const int64_t slab_stride = (int64_t)NPpad * ldk;
-    const float* src = d.ws + (int64_t)np * ldk + kq;
+    const int64_t idx = (int64_t)blockIdx.x * EL + e;
+    const bool ok = idx < total;
+    int cqi = 0, t = 0, np = 0;
     float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += src[k * slab_stride];
+    if (ok) {
+        cqi = (int)(idx % d.NQ);
+        const int64_t r = idx / d.NQ;
+        t = (int)(r % T);
+        np = (int)(r / T);
+        const int64_t slab_stride = (int64_t)NPpad * ldk;
+        const float* src = d.ws + (int64_t)np * ldk + (t * d.QC + cqi);
+        for (int k = sp; k < nsplit; k += SPL) s += src[k * slab_stride];
+    }
+    if (SPL > 1) {
+        red[threadIdx.x] = s;
+        __syncthreads();
+        if (sp != 0) return;
+        for (int k = 1; k < SPL; ++k) s += red[k * EL + e];
+    }
+    if (!ok) return;
     float* dst = d.dW + (int64_t)np * d.s_np + (int64_t)cqi * d.s_cq + (int64_t)t * d.s_t;
     *dst = d.accumulate ? (*dst + s) : s;
 }
 
-struct Plan { int tiles_kq, tiles_np, nsplit, rows_per_split, KQ, NPpad; int64_t ws_bytes; };
+struct Plan { int tiles_kq, tiles_np, nsplit, rows_per_split, KQ, NPpad, tile; int64_t ws_bytes; };
 
 inline int make_plan(const vg_wg_desc* d, int dtype, Plan* p) {
     VG_CHECK_ARG(d != nullptr, VG_EINVAL);
@@ -179,21 +342,25 @@ inline int make_plan(const vg_wg_desc* d, int dtype, Plan* p) {
     const int64_t M = (int64_t)d->B * d->GH * d->GW;
     VG_CHECK_ARG(M < (1ll << 31), VG_EINVAL);
     p->KQ = d->TH * d->TW * d->QC;
-    p->tiles_kq = (p->KQ + WG_BKQ - 1) / WG_BKQ;
-    p->tiles_np = (d->PC + WG_BNP - 1) / WG_BNP;
-    p->NPpad = p->tiles_np * WG_BNP;
+    const int tile = dtype == VG_F32 ? WG_BNP : WB_T;          // output tile edge
+    const int srows = dtype == VG_F32 ? WG_BMK : WB_SM;        // pixel rows per stage
+    p->tile = tile;
+    p->tiles_kq = (p->KQ + tile - 1) / tile;
+    p->tiles_np = (d->PC + tile - 1) / tile;
+    p->NPpad = p->tiles_np * tile;
     const int tiles = p->tiles_kq * p->tiles_np;
-    int64_t stages = (M + WG_BMK - 1) / WG_BMK;
+    int64_t stages = (M + srows - 1) / srows;
     int nsplit = (int)((1024 + tiles - 1) / tiles);
-    // at least 8 stages of work per workgroup, at most 1024 splits
-    if (nsplit > stages / 8) nsplit = (int)(stages / 8);
+    // at least 8 (f32) / 4 (bf16) stages of work per workgroup, at most 1024 splits
+    const int min_stages = dtype == VG_F32 ? 8 : 4;
+    if (nsplit > stages / min_stages) nsplit = (int)(stages / min_stages);
     if (nsplit < 1) nsplit = 1;
     if (nsplit > 1024) nsplit = 1024;
-    int64_t rps = ((stages + nsplit - 1) / nsplit) * WG_BMK;
+    int64_t rps = ((stages + nsplit - 1) / nsplit) * srows;
     nsplit = (int)((M + rps - 1) / rps);
     p->nsplit = nsplit;
     p->rows_per_split = (int)rps;
-    p->ws_bytes = (int64_t)nsplit * p->NPpad * (int64_t)(p->tiles_kq * WG_BKQ) * 4;
+    p->ws_bytes = (int64_t)nsplit * p->NPpad * (int64_t)(p->tiles_kq * tile) * 4;
     return 0;
 }
 
@@ -217,11 +384,13 @@ extern "C" int vg_wgrad(const vg_wg_desc* d, int dtype, void* stream) {
     if (dtype == VG_F32)
         hipLaunchKernelGGL(wgrad_kernel<VG_F32>, grid, dim3(256), 0, s, *d, p.rows_per_split, p.KQ, p.NPpad);
     else
-        hipLaunchKernelGGL(wgrad_kernel<VG_BF16>, grid, dim3(256), 0, s, *d, p.rows_per_split, p.KQ, p.NPpad);
+        hipLaunchKernelGGL(wgrad_bf16_kernel, grid, dim3(256), 0, s, *d, p.rows_per_split, p.KQ, p.NPpad);
     rc = VG_LAUNCH_RC();
     if (rc) return rc;
     const int64_t total = (int64_t)d->NP * d->TH * d->TW * d->NQ;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, *d, p.nsplit,
-                       p.NPpad, p.tiles_kq * WG_BKQ);
+    const int SPL = p.nsplit >= 64 ? 32 : (p.nsplit >= 8 ? 8 : 1);
+    const int EL = 256 / SPL;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + EL - 1) / EL)), dim3(256), 0, s, *d, p.nsplit,
+                       p.NPpad, p.tiles_kq * p.tile, SPL);
     return VG_LAUNCH_RC();
 }
