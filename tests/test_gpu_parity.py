@@ -156,7 +156,7 @@ def test_teacher_forced_steps_adam_and_batchnorm_state(S, B):
     o = R.RefVAEGAN(img_size=S, seed=42)
     for step in range(3):
         sync_from_oracle(o, e, g, d, tr)
-        before = {k: v.detach().clone() for st in (o.E, o.G, o.D) for k, v in st.items()}
+        before_all = {id(st): {k: v.detach().clone() for k, v in st.items()} for st in (o.E, o.G, o.D)}
         real, ez, er, ec = make_inputs(B, S, 9000 + S + step)
         ref = o.train_step(real, ez, er, ec, 25)
         got = tr.loss_dict(tr.train_step(real.to(DEV), 25, ez.to(DEV), er.to(DEV), ec.to(DEV)), 25)
@@ -164,6 +164,7 @@ def test_teacher_forced_steps_adam_and_batchnorm_state(S, B):
             assert rel(got[n], ref[n]) <= 2e-4, f"S={S} forced step {step} {n}: hip {got[n]} oracle {ref[n]}"
         for m, st, opt, ro in ((e, o.E, tr.opt_E, o.opt_E), (g, o.G, tr.opt_G, o.opt_G), (d, o.D, tr.opt_D, o.opt_D)):
             assert float(opt.state_dev[0]) == ro.t
+            before = before_all[id(st)]
             # Adam moments are linear / quadratic in the gradients: bounded like the gradients themselves (the
             # worst generator gradients carry up to 1e-1 of their max as fp32 error in the reference too, see
             # test_all_parameter_gradients_vs_fp64_oracle)

@@ -20,6 +20,7 @@
 //     per-channel (sum, sum of squares) partials for train-mode BatchNorm, reduced
 //     wave -> LDS -> one slab row per workgroup (deterministic, no atomics).
 #include "common.hpp"
+#include <type_traits>
 
 namespace {
 
@@ -31,7 +32,9 @@ __global__ __launch_bounds__(256) void gg_kernel(const vg_gg_desc d) {
     constexpr int TN = BN / WN / 16;
     constexpr int AP = BM / 64;                    // A row passes per chunk
     constexpr int BP = (BN + 63) / 64;             // B row passes per chunk
-    constexpr int STAGE = (BM + BN) * 64;          // bytes per LDS buffer
+    constexpr int KCH = (DT == VG_BF16) ? 2 : 1;   // 64-byte K chunks per barrier (bf16 MFMAs are 16x shorter)
+    constexpr int CHB = (BM + BN) * 64;            // bytes of one chunk image
+    constexpr int STAGE = CHB * KCH;               // bytes per LDS buffer
     static_assert(WM * WN == 4, "4 waves");
     static_assert(BM % 64 == 0, "BM multiple of 64");
 
@@ -50,74 +53,97 @@ __global__ __launch_bounds__(256) void gg_kernel(const vg_gg_desc d) {
     const int lrow = tid >> 2;                     // 0..63
     const int q = tid & 3;                         // 16-byte unit within the chunk
     const int upt = (d.IC * ESZ) >> 4;             // 16-byte units per tap
-    const int k16 = d.TH * d.TW * upt;             // valid units along K
+    const int ntap = d.TH * d.TW;
     const int nchunks = (d.Kp * ESZ) >> 6;
+    const int nstages = (nchunks + KCH - 1) / KCH;
+    const uint32_t pix_bytes = (uint32_t)d.IC * ESZ;
 
-    // ---- per-thread gather bases for its A rows ----
-    int a_img[AP], a_iy[AP], a_ix[AP];
-    bool a_ok[AP];
+    // ---- per-thread gather bases for its A rows: pixel index of tap (0,0) and its (y, x) for the bounds test ----
+    int a_pix[AP], a_iy[AP], a_ix[AP];
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
         const int m = m0 + lrow + 64 * i;
-        a_ok[i] = m < M;
-        const int mm = a_ok[i] ? m : 0;
-        const int b = mm / GHW;
-        const int r = mm - b * GHW;
-        const int gy = r / d.GW;
-        const int gx = r - gy * d.GW;
-        a_img[i] = b * d.IH * d.IW;
-        a_iy[i] = gy * d.SY + d.y0[phase];
-        a_ix[i] = gx * d.SX + d.x0[phase];
+        if (m < M) {
+            const int b = m / GHW;
+            const int r = m - b * GHW;
+            const int gy = r / d.GW;
+            const int gx = r - gy * d.GW;
+            a_iy[i] = gy * d.SY + d.y0[phase];
+            a_ix[i] = gx * d.SX + d.x0[phase];
+            a_pix[i] = (b * d.IH + a_iy[i]) * d.IW + a_ix[i];
+        } else {
+            a_iy[i] = -(1 << 28);                  // fails every bounds test -> zeros
+            a_ix[i] = 0;
+            a_pix[i] = 0;
+        }
     }
     const unsigned char* Xb = reinterpret_cast<const unsigned char*>(d.X);
     const unsigned char* Wb = reinterpret_cast<const unsigned char*>(d.W);
-    const int64_t pix_bytes = (int64_t)d.IC * ESZ;
-    const int64_t wrow_bytes = (int64_t)d.Kp * ESZ;
-    int64_t b_off[BP];
+    const uint32_t wrow_bytes = (uint32_t)d.Kp * ESZ;
+    const unsigned char* b_ptr[BP];
     bool b_ok[BP];
 #pragma unroll
     for (int j = 0; j < BP; ++j) {
         const int n = n0 + lrow + 64 * j;
         b_ok[j] = (lrow + 64 * j < BN) && (n < d.N);
-        b_off[j] = ((int64_t)phase * d.N + (b_ok[j] ? n : 0)) * wrow_bytes;
+        b_ptr[j] = Wb + ((int64_t)phase * d.N + (b_ok[j] ? n : 0)) * wrow_bytes + q * 16;
     }
 
-    u32x4 ra[AP], rb[BP];
-    auto load_chunk = [&](int kc) {
-        const int u = kc * 4 + q;
-        const bool uok = u < k16;
-        const int t = u / upt;
-        const int cu = u - t * upt;
-        const int ta = t / d.TW;
-        const int tb = t - ta * d.TW;
-        const int dy = d.DY * ta, dx = d.DX * tb;
+    // running K position of the NEXT chunk this thread loads: tap (ta, tb), 16-byte unit cu inside the tap
+    int ld_t = q / upt, ld_cu = q - ld_t * upt;
+    int ld_ta = ld_t / d.TW, ld_tb = ld_t - ld_ta * d.TW;
+    uint32_t ld_koff = 0;                          // byte offset of the next chunk inside a packed weight row
+
+    // Two register sets: the loads of stages s+1 AND s+2 are in flight while stage s is multiplied (each stage
+    // otherwise costs one full L2 round trip: the MFMAs of a stage are far shorter than the memory latency).
+    u32x4 ra[2][KCH][AP], rb[2][KCH][BP];
+    auto load_stage = [&](auto SET) {
+        constexpr int rs = decltype(SET)::value;
 #pragma unroll
-        for (int i = 0; i < AP; ++i) {
-            const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
-            const bool ok = a_ok[i] && uok && (unsigned)iy < (unsigned)d.IH && (unsigned)ix < (unsigned)d.IW;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (ok) v = *reinterpret_cast<const u32x4*>(Xb + (int64_t)(a_img[i] + iy * d.IW + ix) * pix_bytes + cu * 16);
-            ra[i] = v;
-        }
+        for (int c = 0; c < KCH; ++c) {
+            const bool uok = ld_t < ntap && ld_koff < wrow_bytes;
+            const int dy = d.DY * ld_ta, dx = d.DX * ld_tb;
+            const int dpix = dy * d.IW + dx;
 #pragma unroll
-        for (int j = 0; j < BP; ++j) {
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (b_ok[j]) v = *reinterpret_cast<const u32x4*>(Wb + b_off[j] + (int64_t)u * 16);
-            rb[j] = v;
+            for (int i = 0; i < AP; ++i) {
+                const bool ok = uok && (unsigned)(a_iy[i] + dy) < (unsigned)d.IH &&
+                                (unsigned)(a_ix[i] + dx) < (unsigned)d.IW;
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (ok) v = *reinterpret_cast<const u32x4*>(Xb + (uint32_t)(a_pix[i] + dpix) * pix_bytes + (uint32_t)ld_cu * 16u);
+                ra[rs][c][i] = v;
+            }
+#pragma unroll
+            for (int j = 0; j < BP; ++j) {
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (b_ok[j] && ld_koff < wrow_bytes) v = *reinterpret_cast<const u32x4*>(b_ptr[j] + ld_koff);
+                rb[rs][c][j] = v;
+            }
+            // advance by one chunk = 4 units
+            ld_koff += 64;
+            ld_cu += 4;
+            while (ld_cu >= upt) {
+                ld_cu -= upt;
+                ++ld_t;
+                if (++ld_tb == d.TW) { ld_tb = 0; ++ld_ta; }
+            }
         }
     };
-    auto store_chunk = [&](int buf) {
-        unsigned char* sa = smem + buf * STAGE;
-        unsigned char* sb = sa + BM * 64;
+    auto store_stage = [&](int buf, auto SET) {
+        constexpr int rs = decltype(SET)::value;
 #pragma unroll
-        for (int i = 0; i < AP; ++i) {
-            const int r = lrow + 64 * i;
-            *reinterpret_cast<u32x4*>(sa + r * 64 + ((q ^ ((-(r >> 2)) & 3)) << 4)) = ra[i];
-        }
+        for (int c = 0; c < KCH; ++c) {
+            unsigned char* sa = smem + buf * STAGE + c * CHB;
+            unsigned char* sb = sa + BM * 64;
 #pragma unroll
-        for (int j = 0; j < BP; ++j) {
-            const int r = lrow + 64 * j;
-            if (r < BN) *reinterpret_cast<u32x4*>(sb + r * 64 + ((q ^ ((-(r >> 2)) & 3)) << 4)) = rb[j];
+            for (int i = 0; i < AP; ++i) {
+                const int r = lrow + 64 * i;
+                *reinterpret_cast<u32x4*>(sa + r * 64 + ((q ^ ((-(r >> 2)) & 3)) << 4)) = ra[rs][c][i];
+            }
+#pragma unroll
+            for (int j = 0; j < BP; ++j) {
+                const int r = lrow + 64 * j;
+                if (r < BN) *reinterpret_cast<u32x4*>(sb + r * 64 + ((q ^ ((-(r >> 2)) & 3)) << 4)) = rb[rs][c][j];
+            }
         }
     };
 
@@ -130,53 +156,89 @@ __global__ __launch_bounds__(256) void gg_kernel(const vg_gg_desc d) {
     const int fr = lane & 15;       // row within the 16x16 operand tile
     const int fg = lane >> 4;       // 16-byte unit (k group)
 
-    load_chunk(0);
-    store_chunk(0);
-    __syncthreads();
-
-    for (int kc = 0; kc < nchunks; ++kc) {
-        const int buf = kc & 1;
-        if (kc + 1 < nchunks) load_chunk(kc + 1);
-        const unsigned char* sa = smem + buf * STAGE;
-        const unsigned char* sb = sa + BM * 64;
-        u32x4 fa[TM], fb[TN];
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    auto compute = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int r = wm * (BM / WM) + i * 16 + fr;
-            fa[i] = *reinterpret_cast<const u32x4*>(sa + r * 64 + ((fg ^ ((-(r >> 2)) & 3)) << 4));
-        }
+        for (int c = 0; c < KCH; ++c) {
+            const unsigned char* sa = smem + buf * STAGE + c * CHB;
+            const unsigned char* sb = sa + BM * 64;
+            u32x4 fa[TM], fb[TN];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int r = wn * (BN / WN) + j * 16 + fr;
-            fb[j] = *reinterpret_cast<const u32x4*>(sb + r * 64 + ((fg ^ ((-(r >> 2)) & 3)) << 4));
-        }
-        if constexpr (DT == VG_F32) {
+            for (int i = 0; i < TM; ++i) {
+                const int r = wm * (BM / WM) + i * 16 + fr;
+                fa[i] = *reinterpret_cast<const u32x4*>(sa + r * 64 + ((fg ^ ((-(r >> 2)) & 3)) << 4));
+            }
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
+            for (int j = 0; j < TN; ++j) {
+                const int r = wn * (BN / WN) + j * 16 + fr;
+                fb[j] = *reinterpret_cast<const u32x4*>(sb + r * 64 + ((fg ^ ((-(r >> 2)) & 3)) << 4));
+            }
+            if constexpr (DT == VG_F32) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                __uint_as_float(fa[i][kk]), __uint_as_float(fb[j][kk]), acc[i][j], 0, 0, 0);
+            } else {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                            __uint_as_float(fa[i][kk]), __uint_as_float(fb[j][kk]), acc[i][j], 0, 0, 0);
-        } else {
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        __builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
+            }
         }
-        if (kc + 1 < nchunks) store_chunk(buf ^ 1);
+    };
+
+    // prologue: stage 0 -> LDS buffer 0; stages 1 and 2 in flight in register sets 1 and 0
+    load_stage(S0{});
+    store_stage(0, S0{});
+    if (nstages > 1) load_stage(S1{});
+    if (nstages > 2) load_stage(S0{});
+    __syncthreads();
+    // steady state, unrolled by two so that register-set indices are compile-time constants:
+    //   compute(s) ; store(s+1) from its set ; refill that set with stage s+3 ; barrier
+    for (int ks = 0; ks < nstages; ks += 2) {
+        compute(0);
+        if (ks + 1 < nstages) store_stage(1, S1{});
+        if (ks + 3 < nstages) load_stage(S1{});
+        __syncthreads();
+        if (ks + 1 >= nstages) break;
+        compute(1);
+        if (ks + 2 < nstages) store_stage(0, S0{});
+        if (ks + 4 < nstages) load_stage(S0{});
         __syncthreads();
     }
 
     // ---------------- epilogue ----------------
+    // (1) BatchNorm partial statistics straight from the accumulators (valid rows / real channels only);
+    // (2) the C tile goes through LDS so that every lane writes one 16-byte run of channels of one output pixel
+    //     (NHWC) instead of 2/4-byte scatters; output pixel offsets come from an LDS table filled once per
+    //     workgroup (no per-element integer division for the sub-pixel scatter).
+    __shared__ int opix_tab[BM];
     const bool flat = (d.nphase == 1 && d.OSY == 1 && d.OSX == 1 && d.GH == d.OH && d.GW == d.OW);
-    const bool want_stats = d.stats != nullptr;
-    float s1[TN], s2[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    for (int r = tid; r < BM; r += 256) {
+        const int m = m0 + r;
+        int op = -1;
+        if (m < M) {
+            if (flat) {
+                op = m;
+            } else {
+                const int b = m / GHW;
+                const int rem = m - b * GHW;
+                const int gy = rem / d.GW;
+                const int gx = rem - gy * d.GW;
+                const int oy = gy * d.OSY + d.ooy[phase];
+                const int ox = gx * d.OSX + d.oox[phase];
+                if (oy < d.OH && ox < d.OW) op = (b * d.OH + oy) * d.OW + ox;
+            }
+        }
+        opix_tab[r] = op;
+    }
     float biasv[TN];
     int ncol[TN];
 #pragma unroll
@@ -184,45 +246,30 @@ __global__ __launch_bounds__(256) void gg_kernel(const vg_gg_desc d) {
         ncol[j] = n0 + wn * (BN / WN) + j * 16 + fr;
         biasv[j] = (d.bias != nullptr && ncol[j] < d.N) ? d.bias[ncol[j]] : 0.f;
     }
-    unsigned char* Yb = reinterpret_cast<unsigned char*>(d.Y);
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = m0 + wm * (BM / WM) + i * 16 + fg * 4 + r;
-            bool ok = m < M;
-            int64_t opix = m;
-            if (!flat && ok) {
-                const int b = m / GHW;
-                const int rem = m - b * GHW;
-                const int gy = rem / d.GW;
-                const int gx = rem - gy * d.GW;
-                const int oy = gy * d.OSY + d.ooy[phase];
-                const int ox = gx * d.OSX + d.oox[phase];
-                ok = (oy < d.OH) && (ox < d.OW);
-                opix = ((int64_t)b * d.OH + oy) * d.OW + ox;
-            }
-            if (!ok) continue;
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = ncol[j];
-                if (n < d.OC) {
-                    float v = 0.f;
-                    if (n < d.N) {
-                        v = acc[i][j][r] + biasv[j];
-                        s1[j] += v;
-                        s2[j] += v * v;
-                    }
-                    store1<DT>(Yb, opix * d.OC + n, v);
-                }
-            }
-        }
-    }
-    if (want_stats) {
-        float* red = reinterpret_cast<float*>(smem);            // [WM][BN][2]
+            for (int r = 0; r < 4; ++r) acc[i][j][r] += biasv[j];
+    __syncthreads();                                   // opix_tab visible; main-loop LDS reads are done
+
+    if (d.stats != nullptr) {
+        float* red = reinterpret_cast<float*>(smem);   // [WM][BN][2]
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            float a = s1[j], b = s2[j];
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = wm * (BM / WM) + i * 16 + fg * 4 + r;
+                    if (opix_tab[row] >= 0) {
+                        const float v = acc[i][j][r];
+                        a += v;
+                        b += v * v;
+                    }
+                }
             a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
             b += __shfl_xor(b, 16); b += __shfl_xor(b, 32);
             if (fg == 0) {
@@ -240,6 +287,44 @@ __global__ __launch_bounds__(256) void gg_kernel(const vg_gg_desc d) {
             d.stats[(part * 2 + 0) * d.N + n0 + tid] = a;
             d.stats[(part * 2 + 1) * d.N + n0 + tid] = b;
         }
+        __syncthreads();
+    }
+
+    // C tile staging: pitch padded by 16 B; the tile is written in NPASS row blocks when it exceeds the LDS buffers
+    constexpr int NPASS = (BM * (BN * ESZ + 16) <= 2 * STAGE) ? 1 : WM;
+    constexpr int PROWS = BM / NPASS;
+    constexpr int CPITCH = BN * ESZ + ((PROWS * (BN * ESZ + 16) <= 2 * STAGE) ? 16 : 0);
+    static_assert(PROWS * CPITCH <= 2 * STAGE, "C tile pass does not fit in LDS");
+    constexpr int SEGS = BN * ESZ / 16;                // 16-byte segments per tile row
+    unsigned char* Yb = reinterpret_cast<unsigned char*>(d.Y);
+    const int oc_bytes = d.OC * ESZ;
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+        const bool mine = (NPASS == 1) || (wm == pass);
+        if (mine) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = wm * (BM / WM) + i * 16 + fg * 4 + r - pass * PROWS;
+                        const int col = wn * (BN / WN) + j * 16 + fr;
+                        typename E::type* dst = reinterpret_cast<typename E::type*>(smem + row * CPITCH) + col;
+                        *dst = E::from_f32(acc[i][j][r]);
+                    }
+        }
+        __syncthreads();
+        for (int u = tid; u < PROWS * SEGS; u += 256) {
+            const int row = u / SEGS, seg = u - row * SEGS;
+            const int op = opix_tab[pass * PROWS + row];
+            const int cb = n0 * ESZ + seg * 16;        // byte offset of this segment inside the output pixel
+            if (op >= 0 && cb < oc_bytes) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(smem + row * CPITCH + seg * 16);
+                *reinterpret_cast<u32x4*>(Yb + (int64_t)op * oc_bytes + cb) = v;
+            }
+        }
+        if (pass + 1 < NPASS) __syncthreads();
     }
 }
 
@@ -270,9 +355,11 @@ inline int validate(const vg_gg_desc* d, int dtype) {
     VG_CHECK_ARG(d->TH > 0 && d->TW > 0 && d->nphase >= 1 && d->nphase <= VG_MAX_PHASE, VG_EINVAL);
     VG_CHECK_ARG((d->IC * esz) % 16 == 0, VG_EALIGN);
     VG_CHECK_ARG((d->Kp * esz) % 64 == 0 && d->Kp >= d->TH * d->TW * d->IC, VG_EALIGN);
-    VG_CHECK_ARG(vg_aligned16(d->X) && vg_aligned16(d->W), VG_EALIGN);
+    VG_CHECK_ARG(vg_aligned16(d->X) && vg_aligned16(d->W) && vg_aligned16(d->Y), VG_EALIGN);
+    VG_CHECK_ARG((d->OC * esz) % 16 == 0, VG_EALIGN);
     VG_CHECK_ARG((int64_t)d->B * d->GH * d->GW < (1ll << 31), VG_EINVAL);
     VG_CHECK_ARG((int64_t)d->B * d->IH * d->IW < (1ll << 31), VG_EINVAL);
+    VG_CHECK_ARG((int64_t)d->B * d->IH * d->IW * d->IC * esz < (1ll << 32), VG_ENOSUP);   // 32-bit gather offsets
     // every output pixel written by some phase must be inside the tensor (skips are allowed)
     for (int p = 0; p < d->nphase; ++p) VG_CHECK_ARG(d->ooy[p] >= 0 && d->oox[p] >= 0, VG_EINVAL);
     return 0;

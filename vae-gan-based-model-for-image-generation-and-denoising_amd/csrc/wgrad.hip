@@ -296,37 +296,54 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const vg_wg_desc d, int
             }
 }
 
-// Sum the split slabs in fixed order and scatter into the reference parameter layout.  A block is EL output
-// elements x SPL split lanes (EL*SPL = 256): with few output elements and ~1000 slabs a one-thread-per-element
-// loop is a serial chain of ~1000 HBM latencies, so the slabs are walked by SPL lanes and combined through LDS.
+// Sum the split slabs in fixed order and write the reference parameter layout.  One thread owns one
+// (np, cq) pair and walks its T filter taps: slab reads are coalesced across cq, and the T taps of a weight
+// row are contiguous in OIHW (s_t == 1), so every thread writes one contiguous run instead of 4-byte scatters.
+// A block is EL pairs x SPL split lanes (EL*SPL = 256): with few outputs and ~1000 slabs a plain per-element
+// loop is a serial chain of HBM latencies, so the slabs are walked by SPL lanes and combined through LDS.
+template <int TT>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const vg_wg_desc d, int nsplit, int NPpad, int ldk, int SPL) {
     __shared__ float red[256];
     const int EL = 256 / SPL;
     const int e = threadIdx.x % EL, sp = threadIdx.x / EL;
     const int T = d.TH * d.TW;
-    const int64_t total = (int64_t)d.NP * T * d.NQ;
+    const int64_t total = (int64_t)d.NP * d.NQ;
     const int64_t idx = (int64_t)blockIdx.x * EL + e;
     const bool ok = idx < total;
-    int cqi = 0, t = 0, np = 0;
-    float s = 0.f;
-    if (ok) {
-        cqi = (int)(idx % d.NQ);
-        const int64_t r = idx / d.NQ;
-        t = (int)(r % T);
-        np = (int)(r / T);
-        const int64_t slab_stride = (int64_t)NPpad * ldk;
-        const float* src = d.ws + (int64_t)np * ldk + (t * d.QC + cqi);
-        for (int k = sp; k < nsplit; k += SPL) s += src[k * slab_stride];
+    const int cqi = ok ? (int)(idx % d.NQ) : 0;
+    const int np = ok ? (int)(idx / d.NQ) : 0;
+    const int64_t slab_stride = (int64_t)NPpad * ldk;
+    const float* src = d.ws + (int64_t)np * ldk + cqi;
+    float* dst = d.dW + (int64_t)np * d.s_np + (int64_t)cqi * d.s_cq;
+    for (int t0 = 0; t0 < T; t0 += TT) {
+        float s[TT];
+#pragma unroll
+        for (int j = 0; j < TT; ++j) s[j] = 0.f;
+        if (ok) {
+            for (int k = sp; k < nsplit; k += SPL) {
+#pragma unroll
+                for (int j = 0; j < TT; ++j)
+                    if (t0 + j < T) s[j] += src[k * slab_stride + (int64_t)(t0 + j) * d.QC];
+            }
+        }
+        if (SPL > 1) {
+#pragma unroll
+            for (int j = 0; j < TT; ++j) {
+                __syncthreads();
+                red[threadIdx.x] = s[j];
+                __syncthreads();
+                if (sp == 0) for (int k = 1; k < SPL; ++k) s[j] += red[k * EL + e];
+            }
+        }
+        if (ok && sp == 0) {
+#pragma unroll
+            for (int j = 0; j < TT; ++j)
+                if (t0 + j < T) {
+                    float* q = dst + (int64_t)(t0 + j) * d.s_t;
+                    *q = d.accumulate ? (*q + s[j]) : s[j];
+                }
+        }
     }
-    if (SPL > 1) {
-        red[threadIdx.x] = s;
-        __syncthreads();
-        if (sp != 0) return;
-        for (int k = 1; k < SPL; ++k) s += red[k * EL + e];
-    }
-    if (!ok) return;
-    float* dst = d.dW + (int64_t)np * d.s_np + (int64_t)cqi * d.s_cq + (int64_t)t * d.s_t;
-    *dst = d.accumulate ? (*dst + s) : s;
 }
 
 struct Plan { int tiles_kq, tiles_np, nsplit, rows_per_split, KQ, NPpad, tile; int64_t ws_bytes; };
@@ -350,7 +367,7 @@ inline int make_plan(const vg_wg_desc* d, int dtype, Plan* p) {
     p->NPpad = p->tiles_np * tile;
     const int tiles = p->tiles_kq * p->tiles_np;
     int64_t stages = (M + srows - 1) / srows;
-    int nsplit = (int)((1024 + tiles - 1) / tiles);
+    int nsplit = (int)((512 + tiles - 1) / tiles);            // ~2 workgroups per CU
     // at least 8 (f32) / 4 (bf16) stages of work per workgroup, at most 1024 splits
     const int min_stages = dtype == VG_F32 ? 8 : 4;
     if (nsplit > stages / min_stages) nsplit = (int)(stages / min_stages);
@@ -387,10 +404,13 @@ extern "C" int vg_wgrad(const vg_wg_desc* d, int dtype, void* stream) {
         hipLaunchKernelGGL(wgrad_bf16_kernel, grid, dim3(256), 0, s, *d, p.rows_per_split, p.KQ, p.NPpad);
     rc = VG_LAUNCH_RC();
     if (rc) return rc;
-    const int64_t total = (int64_t)d->NP * d->TH * d->TW * d->NQ;
+    const int64_t total = (int64_t)d->NP * d->NQ;
     const int SPL = p.nsplit >= 64 ? 32 : (p.nsplit >= 8 ? 8 : 1);
     const int EL = 256 / SPL;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + EL - 1) / EL)), dim3(256), 0, s, *d, p.nsplit,
-                       p.NPpad, p.tiles_kq * p.tile, SPL);
+    const dim3 rgrid((unsigned)((total + EL - 1) / EL));
+    if (d->TH * d->TW >= 16)
+        hipLaunchKernelGGL(wgrad_reduce_kernel<16>, rgrid, dim3(256), 0, s, *d, p.nsplit, p.NPpad, p.tiles_kq * p.tile, SPL);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel<4>, rgrid, dim3(256), 0, s, *d, p.nsplit, p.NPpad, p.tiles_kq * p.tile, SPL);
     return VG_LAUNCH_RC();
 }
