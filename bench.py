@@ -72,6 +72,8 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch")
     ap.add_argument("--dtype", default=os.environ.get("VAEGAN_BENCH_DTYPE", "fp32"), choices=["fp32", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("VAEGAN_BENCH_GRAPH", "1")),
+                    help="1: replay the iteration from one captured hipGraph (single GPU only)")
     ap.add_argument("--elide-dead-grads", action="store_true",
                     help="skip the D weight gradients of the generator-loss pass that the reference computes and discards")
     args = ap.parse_args()
@@ -82,11 +84,17 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             sys.exit("launch with torch.distributed.run for --gpus > 1 (see module docstring)")
+    ndev = torch.cuda.device_count()
+    local = local % max(ndev, 1)            # rehearsals put several ranks on one card (gloo); the driver uses 1 rank/GPU
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("VAEGAN_DIST_BACKEND", "nccl")      # "nccl" == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import vaegan_amd as V
     from importlib import import_module
@@ -111,9 +119,11 @@ def main():
     real, ez, er, ec = (t.to(dev) for t in make_inputs(B, S, 1234 + rank))
     epoch = 60
 
-    for _ in range(args.warmup):
-        tr.train_step(real, epoch, ez, er, ec)
-    timer = ops.KernelTimer() if rank == 0 else None
+    use_graph = bool(args.graph) and world == 1
+    step_fn = tr.train_step_graphed if use_graph else tr.train_step
+    for _ in range(max(args.warmup, 2 if use_graph else 0)):
+        step_fn(real, epoch, ez, er, ec)
+    timer = ops.KernelTimer() if (rank == 0 and not use_graph) else None
     ops.set_timer(timer)
     torch.cuda.synchronize()
     if world > 1:
@@ -121,7 +131,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        losses = tr.train_step(real, epoch, ez, er, ec)
+        losses = step_fn(real, epoch, ez, er, ec)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -143,6 +153,15 @@ def main():
     assert all(v == v and abs(v) < 1e6 for v in ld.values()), f"non-finite losses: {ld}"
 
     # ---- roofline of the dominant kernel family (implicit-GEMM conv fprop+dgrad), measured live ----
+    if timer is None:
+        # graph replay: per-launch HIP events cannot be recorded inside the captured region, so the kernel
+        # family is timed in an extra eager pass of the same steps right after the timed region
+        timer = ops.KernelTimer()
+        ops.set_timer(timer)
+        for _ in range(args.steps):
+            tr.train_step(real, epoch, ez, er, ec)
+        torch.cuda.synchronize()
+        ops.set_timer(None)
     fam = timer.summary()
     gg = fam.get("gather_gemm", dict(launches=0, ms=1e-9, flops=0, bytes=0))
     wg = fam.get("wgrad", dict(launches=0, ms=1e-9, flops=0, bytes=0))
@@ -153,11 +172,11 @@ def main():
                 "launches_per_step": gg["launches"] // args.steps,
                 "avg_launch_us": round(gg["ms"] * 1e3 / max(gg["launches"], 1), 2),
                 "alg_gflop_per_launch": round(gg["flops"] / max(gg["launches"], 1) / 1e9, 3),
-                "share_of_step": round(gg["ms"] / (elapsed * 1e3), 3),
+                "share_of_step": round(gg["ms"] / args.steps / ms, 3),
                 "alg_bytes_gbs": round(gg["bytes"] / (gg["ms"] * 1e-3) / 1e9, 1),
                 "wgrad": {"achieved": round(wg["flops"] / (wg["ms"] * 1e-3) / 1e12, 2),
                           "launches_per_step": wg["launches"] // args.steps,
-                          "share_of_step": round(wg["ms"] / (elapsed * 1e3), 3)},
+                          "share_of_step": round(wg["ms"] / args.steps / ms, 3)},
                 "step_alg_tflops": round(ALG_GFLOP_PER_IMAGE.get(S, 0) * B / ms, 2)}
     out = {"metric": "images/sec/GPU VAE-GAN train step", "value": round(value, 1), "unit": "images/sec",
            "per_gpu": round(value / world, 1), "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -166,7 +185,7 @@ def main():
            "config": {"workload": f"CelebA-shaped {S}x{S} VAE-GAN full train step (E+G+5xD fwd, all bwd, 4 Adam), "
                                   f"batch {B}/GPU, global batch {B * world}", "img_size": S, "per_gpu_batch": B,
                       "global_batch": B * world, "parallelism": f"dp{world}", "epoch_kl_weight": 0.1,
-                      "elide_dead_grads": bool(args.elide_dead_grads)},
+                      "elide_dead_grads": bool(args.elide_dead_grads), "hip_graph": use_graph},
            "losses": {k: round(v, 5) for k, v in ld.items()},
            "roofline": roofline}
     if world == 1 and not args.no_cpu_baseline:

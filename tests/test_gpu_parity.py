@@ -241,6 +241,25 @@ def test_step_is_bitwise_deterministic():
         assert torch.equal(a, b)
 
 
+def test_graph_replay_is_bitwise_identical_to_eager():
+    """train_step_graphed (eager warm-up, capture, replays) == train_step, bit for bit, incl. BN counters."""
+    res = []
+    for graphed in (False, True):
+        e, g, d, tr = build(64)
+        fn = tr.train_step_graphed if graphed else tr.train_step
+        for step in range(4):
+            real, ez, er, ec = (t.to(DEV) for t in make_inputs(4, 64, 7064 + step))
+            l = fn(real, 60, ez, er, ec)
+        res.append((l[:5].cpu().clone(), tr.opt_E.flat_p.cpu().clone(), tr.opt_G.flat_p.cpu().clone(),
+                    tr.opt_D.flat_p.cpu().clone(), {k: v.cpu().clone() for k, v in d.state_dict().items()},
+                    (tr.opt_D.steps, float(tr.opt_D.state_dev[0]))))
+    for a, b in zip(res[0][:4], res[1][:4]):
+        assert torch.equal(a, b)
+    for k in res[0][4]:
+        assert torch.equal(res[0][4][k], res[1][4][k]), k
+    assert res[0][5] == res[1][5] == (8, 8.0)
+
+
 # --------------------------------------------------------------------------------------------------
 def test_dropin_autograd_path_matches_direct_trainer_and_oracle():
     """The reference trainer's own code shape (vaegan_code.py:65-135: module calls, torch ops, .backward(),

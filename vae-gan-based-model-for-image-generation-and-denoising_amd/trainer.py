@@ -36,6 +36,8 @@ class VAEGANTrainer:
         self.dt = dts.pop()
         self.latent = encoder.latent_dim
         self.losses = None
+        self._graph = None              # (key, hipGraph, static inputs, static losses)
+        self._warm_key = None
 
     def train(self):
         self.E.train(), self.G.train(), self.D.train()                                         # :56-58
@@ -110,6 +112,66 @@ class VAEGANTrainer:
         self.opt_G.step()
         self.losses = losses
         return losses
+
+    # ---- hipGraph replay of the whole iteration -------------------------------------------------------------
+    def train_step_graphed(self, real: torch.Tensor, epoch: int, eps_z: Optional[torch.Tensor] = None,
+                           eps_real: Optional[torch.Tensor] = None,
+                           eps_recon: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Same iteration as train_step, replayed from one captured hipGraph (~400 kernel launches become one
+        graph launch).  Every call performs exactly one training iteration: the first call with a new
+        (shape, KL weight, noise mode) runs eagerly (it also sizes the workspaces), the second captures and
+        replays, later calls replay.  Inputs are copied into static buffers; noise is either injected on every
+        call or drawn on the device inside the graph (torch's graph-safe Philox state).
+        Not used with a gradient reducer (collectives stay eager)."""
+        if self.reducer is not None:
+            return self.train_step(real, epoch, eps_z, eps_real, eps_recon)
+        inject = eps_z is not None
+        if inject and (eps_real is None or eps_recon is None):
+            raise ValueError("inject all three noise tensors or none")
+        key = (tuple(real.shape), float(self.alpha_kl * min(1.0, epoch / 50)), inject, self.E.training)
+        if self._graph is not None and self._graph[0] == key:
+            _, g, sin, sout = self._graph
+            sin[0].copy_(real)
+            if inject:
+                sin[1].copy_(eps_z), sin[2].copy_(eps_real), sin[3].copy_(eps_recon)
+            g.replay()
+            self._advance_host_counters()
+            self.losses = sout
+            return sout
+        if self._warm_key != key:
+            self._warm_key = key
+            self._graph = None
+            return self.train_step(real, epoch, eps_z, eps_real, eps_recon)
+        sin = [real.clone()] + ([eps_z.clone(), eps_real.clone(), eps_recon.clone()] if inject else [None] * 3)
+        for eng in (self.E._engine, self.G._engine, self.D._engine):
+            eng.invalidate()                       # the captured sequence must contain the operand re-packs
+        torch.cuda.synchronize()
+        ticks = [m._engine.pending_bn_ticks for m in (self.E, self.G, self.D)]
+        steps = [o.steps for o in (self.opt_E, self.opt_G, self.opt_D)]
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            sout = self.train_step(sin[0], epoch, sin[1], sin[2], sin[3])
+        # capture only records: undo the host-side counter changes it made, then replay for real
+        for m, t in zip((self.E, self.G, self.D), ticks):
+            m._engine.pending_bn_ticks = t
+        for o, st in zip((self.opt_E, self.opt_G, self.opt_D), steps):
+            o.steps = st
+        self._graph = (key, g, sin, sout)
+        g.replay()
+        self._advance_host_counters()
+        self.losses = sout
+        return sout
+
+    def _advance_host_counters(self) -> None:
+        """What one iteration does to host-side mirrors: BatchNorm forward counts (E 1, G 1, D 2*d_iters+1) and
+        optimizer step counts (the authoritative Adam step counter lives on the device)."""
+        if self.E.training:
+            self.E._engine.pending_bn_ticks += 1
+            self.G._engine.pending_bn_ticks += 1
+            self.D._engine.pending_bn_ticks += 2 * self.d_iters + 1
+        self.opt_E.steps += 1
+        self.opt_G.steps += 1
+        self.opt_D.steps += self.d_iters
 
     def loss_dict(self, losses: Optional[torch.Tensor] = None, epoch: Optional[int] = None) -> Dict[str, float]:
         """Host copy of the last step's losses (one device sync, like the reference's .item() calls :125-127)."""
