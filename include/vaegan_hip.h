@@ -118,9 +118,13 @@ typedef struct vg_pack_desc {
     int32_t nphase, N, C, IC, TH, TW, Kp;
     int32_t s_n, s_c, KW;
     int32_t kh0[VG_MAX_PHASE], kw0[VG_MAX_PHASE], kh_step, kw_step;
-    int32_t tap_in_n, KHW;
+    int32_t tap_in_n, KHW;          /* KHW = taps of the FULL kernel (KH*KW) */
 } vg_pack_desc;
 int vg_pack_weights(const vg_pack_desc* d, int dtype, void* stream);
+/* Same, for a whole network in one launch: `descs_dev` is an array of n descriptors in DEVICE memory (their
+ * src/dst pointers are stable: parameters live in the optimizer's flat buffer); max_elems = largest
+ * nphase*N*Kp among them (sizes the grid). */
+int vg_pack_weights_multi(const vg_pack_desc* descs_dev, int n, int64_t max_elems, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * BatchNorm (train / eval) + activation, NHWC rows = B*H*W, C channels (C % 4 == 0).

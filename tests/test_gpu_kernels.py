@@ -290,3 +290,36 @@ def test_adam_against_torch_optim_golden(ops, golden_dir):
     np.testing.assert_allclose(m.cpu().numpy(), g["exp_avg"], rtol=2e-6, atol=1e-9)
     np.testing.assert_allclose(v.cpu().numpy(), g["exp_avg_sq"], rtol=2e-6, atol=1e-12)
     assert float(state[0]) == g["grads"].shape[0]
+
+
+@pytest.mark.parametrize("dtype", [G.F32, G.BF16])
+def test_tiled_multi_pack_equals_reference_pack(ops, dtype):
+    """vg_pack_weights_multi (LDS-tiled, one launch for many operands) == vg_pack_weights, bit for bit, for
+    every operand form the networks use (direct, 4-phase transposed, taps-in-N, linear incl. many-tap kernels)."""
+    g = torch.Generator().manual_seed(11)
+    cases = []
+    for fn, a, wshape in [
+        (G.conv_fprop, (2, 64, 64, 3, 64, 4, 2, 1), (64, 3, 4, 4)),
+        (G.conv_dgrad, (2, 64, 64, 3, 64, 4, 2, 1), (64, 3, 4, 4)),
+        (G.conv_fprop, (2, 14, 14, 64, 128, 4, 2, 0), (128, 64, 4, 4)),
+        (G.conv_dgrad, (2, 31, 31, 32, 64, 4, 2, 0), (64, 32, 4, 4)),
+        (G.convT_fprop, (2, 1, 1, 100, 256, 4, 1, 0), (100, 256, 4, 4)),
+        (G.convT_dgrad, (2, 1, 1, 100, 256, 4, 1, 0), (100, 256, 4, 4)),
+        (G.convT_fprop, (2, 8, 8, 128, 72, 4, 2, 1), (128, 72, 4, 4)),
+        (G.convT_dgrad, (2, 8, 8, 128, 72, 4, 2, 1), (128, 72, 4, 4)),
+        (G.convT_fprop, (2, 16, 16, 64, 3, 3, 1, 1), (64, 3, 3, 3)),
+        (G.convT_dgrad, (2, 16, 16, 64, 3, 3, 1, 1), (64, 3, 3, 3)),
+        (G.conv_fprop, (2, 4, 4, 512, 1, 4, 1, 0), (1, 512, 4, 4)),
+    ]:
+        _, pk = fn(*a, dtype)
+        cases.append((pk, torch.randn(wshape, generator=g).to(DEV)))
+    for H, C, N in ((2, 256, 200), (6, 40, 24)):               # 6x6 = 36 taps: more than one tap tile
+        w = torch.randn(N, C * H * H, generator=g).to(DEV)
+        cases.append((G.linear_fprop(2, H, H, C, N, dtype)[1], w))
+        cases.append((G.linear_dgrad(2, H, H, C, N, dtype)[1], w))
+    outs = [torch.full((pk.numel(),), 7.0, device=DEV).to(ops.TORCH_DT[dtype]) for pk, _ in cases]
+    table = ops.pack_table([ops.pack_desc(pk, w, o) for (pk, w), o in zip(cases, outs)], DEV)
+    ops.pack_weights_multi(table, len(cases), max(pk.numel() for pk, _ in cases), dtype)
+    for (pk, w), o in zip(cases, outs):
+        ref = ops.pack_weights(pk, w, dtype)
+        assert torch.equal(o, ref), pk

@@ -5,7 +5,7 @@
 namespace {
 
 template <int DT>
-__global__ void pack_kernel(const vg_pack_desc d) {
+__device__ __forceinline__ void pack_body(const vg_pack_desc& d) {
     const int64_t total = (int64_t)d.nphase * d.N * d.Kp;
     const int T = d.TH * d.TW;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -31,6 +31,96 @@ __global__ void pack_kernel(const vg_pack_desc d) {
             }
         }
         store1<DT>(d.dst, idx, v);
+    }
+}
+
+template <int DT>
+__global__ void pack_kernel(const vg_pack_desc d) { pack_body<DT>(d); }
+
+// All operand copies of one network in ONE launch: descriptor table in device memory, blockIdx.y = descriptor.
+// Tiled through LDS: a block owns PK_NT rows (n) x PK_CT channels (c) x up to PK_TT filter taps of the SOURCE
+// tensor, reads them along the source's fastest dimensions (whole 64..1024-byte runs instead of 4-byte gathers
+// with a 64-byte stride), and writes the K-major operand rows of every sub-pixel phase with the channel index
+// fastest (128-byte runs).  Each source element is read exactly once per operand.
+constexpr int PK_NT = 4, PK_CT = 64, PK_TT = 16;
+
+template <int DT>
+__global__ __launch_bounds__(256) void pack_multi_kernel(const vg_pack_desc* __restrict__ descs) {
+    __shared__ float tile[PK_NT][PK_CT][PK_TT + 1];
+    const vg_pack_desc d = descs[blockIdx.y];
+    const int rowsN = d.tap_in_n ? d.N / d.KHW : d.N;           // rows of the source "n" index
+    const int ctiles = (d.IC + PK_CT - 1) / PK_CT;
+    const int ntiles = (rowsN + PK_NT - 1) / PK_NT;
+    const int ttiles = (d.KHW + PK_TT - 1) / PK_TT;
+    const int nblocks = ctiles * ntiles * ttiles;
+    const int T = d.TH * d.TW;
+    for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+        const int ct = blk % ctiles;
+        const int nt = (blk / ctiles) % ntiles;
+        const int tt = blk / (ctiles * ntiles);
+        const int c0 = ct * PK_CT, n0 = nt * PK_NT, tap0 = tt * PK_TT;
+        const int ntap = min(PK_TT, d.KHW - tap0);
+        __syncthreads();
+        // ---- load: order the (n, c, tap) enumeration so consecutive threads walk the source contiguously ----
+        const int cnt = PK_NT * PK_CT * ntap;
+        for (int e = threadIdx.x; e < cnt; e += 256) {
+            int nn, cc, tp;
+            tp = e % ntap;
+            const int r = e / ntap;
+            if (d.s_c <= d.s_n) { cc = r % PK_CT; nn = r / PK_CT; }       // [n][c][tap] source (c stride = taps)
+            else { nn = r % PK_NT; cc = r / PK_NT; }                      // [c][n][tap] source (n stride = taps)
+            const int n = n0 + nn, c = c0 + cc;
+            float v = 0.f;
+            if (n < rowsN && c < d.C) v = d.src[(int64_t)n * d.s_n + (int64_t)c * d.s_c + tap0 + tp];
+            tile[nn][cc][tp] = v;
+        }
+        __syncthreads();
+        // ---- store: channel index fastest ----
+        if (d.tap_in_n) {
+            // dst[(tap*CO + co)][ci]: one K-major row per (tap, co)
+            const int cnt2 = PK_NT * ntap * PK_CT;
+            for (int e = threadIdx.x; e < cnt2; e += 256) {
+                const int cc = e % PK_CT;
+                const int r = e / PK_CT;
+                const int tp = r % ntap, nn = r / ntap;
+                const int n = n0 + nn, c = c0 + cc;
+                if (n < rowsN && c < d.Kp)
+                    store1<DT>(d.dst, ((int64_t)(tap0 + tp) * rowsN + n) * d.Kp + c, c < d.IC ? tile[nn][cc][tp] : 0.f);
+            }
+            // K padding beyond the last channel tile
+            if (ct == ctiles - 1)
+                for (int e = threadIdx.x; e < PK_NT * ntap * (d.Kp - ctiles * PK_CT); e += 256) {
+                    const int w = d.Kp - ctiles * PK_CT;
+                    const int c = ctiles * PK_CT + e % w;
+                    const int r = e / w;
+                    const int tp = r % ntap, n = n0 + r / ntap;
+                    if (n < rowsN) store1<DT>(d.dst, ((int64_t)(tap0 + tp) * rowsN + n) * d.Kp + c, 0.f);
+                }
+            continue;
+        }
+        const int cnt2 = d.nphase * PK_NT * T * PK_CT;
+        for (int e = threadIdx.x; e < cnt2; e += 256) {
+            const int cc = e % PK_CT;
+            int r = e / PK_CT;
+            const int t = r % T; r /= T;
+            const int nn = r % PK_NT;
+            const int p = r / PK_NT;
+            const int a = t / d.TW, b = t - a * d.TW;
+            const int ft = (d.kh0[p] + d.kh_step * a) * d.KW + d.kw0[p] + d.kw_step * b - tap0;
+            const int n = n0 + nn, c = c0 + cc;
+            if (ft >= 0 && ft < ntap && n < d.N && c < d.IC)
+                store1<DT>(d.dst, ((int64_t)p * d.N + n) * d.Kp + (int64_t)t * d.IC + c, tile[nn][cc][ft]);
+        }
+        // K padding [T*IC, Kp) of the rows of this n tile (written once, by the first channel/tap tile)
+        if (ct == 0 && tt == 0) {
+            const int w = d.Kp - T * d.IC;
+            for (int e = threadIdx.x; e < d.nphase * PK_NT * w; e += 256) {
+                const int k = T * d.IC + e % w;
+                const int r = e / w;
+                const int n = n0 + r % PK_NT, p = r / PK_NT;
+                if (n < d.N) store1<DT>(d.dst, ((int64_t)p * d.N + n) * d.Kp + k, 0.f);
+            }
+        }
     }
 }
 
@@ -98,6 +188,18 @@ extern "C" int vg_pack_weights(const vg_pack_desc* d, int dtype, void* stream) {
     if (blocks > 4096) blocks = 4096;
     if (dtype == VG_F32) hipLaunchKernelGGL(pack_kernel<VG_F32>, dim3(blocks), dim3(256), 0, vg_stream(stream), *d);
     else hipLaunchKernelGGL(pack_kernel<VG_BF16>, dim3(blocks), dim3(256), 0, vg_stream(stream), *d);
+    return VG_LAUNCH_RC();
+}
+
+extern "C" int vg_pack_weights_multi(const vg_pack_desc* descs_dev, int n, int64_t max_elems, int dtype,
+                                     void* stream) {
+    VG_CHECK_ARG(descs_dev && n > 0 && n <= 65535 && max_elems > 0, VG_EINVAL);
+    VG_CHECK_ARG(dtype == VG_F32 || dtype == VG_BF16, VG_ENOSUP);
+    int bx = (int)((max_elems + PK_NT * PK_CT * PK_TT - 1) / (PK_NT * PK_CT * PK_TT));     // ~1 tile per block
+    if (bx > 2048) bx = 2048;
+    if (bx < 1) bx = 1;
+    if (dtype == VG_F32) hipLaunchKernelGGL(pack_multi_kernel<VG_F32>, dim3(bx, n), dim3(256), 0, vg_stream(stream), descs_dev);
+    else hipLaunchKernelGGL(pack_multi_kernel<VG_BF16>, dim3(bx, n), dim3(256), 0, vg_stream(stream), descs_dev);
     return VG_LAUNCH_RC();
 }
 

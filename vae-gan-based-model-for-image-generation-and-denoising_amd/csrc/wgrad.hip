@@ -296,52 +296,84 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const vg_wg_desc d, int
             }
 }
 
-// Sum the split slabs in fixed order and write the reference parameter layout.  One thread owns one
-// (np, cq) pair and walks its T filter taps: slab reads are coalesced across cq, and the T taps of a weight
-// row are contiguous in OIHW (s_t == 1), so every thread writes one contiguous run instead of 4-byte scatters.
-// A block is EL pairs x SPL split lanes (EL*SPL = 256): with few outputs and ~1000 slabs a plain per-element
-// loop is a serial chain of HBM latencies, so the slabs are walked by SPL lanes and combined through LDS.
-template <int TT>
+// Sum the split slabs in fixed order and write the reference parameter layout.  One thread owns VC consecutive
+// gathered channels (cq) of one np row and walks its T filter taps: per split lane the slab reads are 16-byte
+// vectors that form whole 128-byte lines across the EL threads of a block, and the T taps of a weight row are
+// contiguous in OIHW (s_t == 1), so every thread writes contiguous runs instead of 4-byte scatters.
+// A block is EL (np, cq-group) pairs x SPL split lanes (EL*SPL = 256): with few outputs and ~1000 slabs a plain
+// per-element loop is a serial chain of HBM latencies, so the slabs are walked by SPL lanes, combined via LDS.
+template <int TT, int VC>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const vg_wg_desc d, int nsplit, int NPpad, int ldk, int SPL) {
-    __shared__ float red[256];
+    extern __shared__ __attribute__((aligned(16))) float red[];      // [SPL][EL*VC][TT] when SPL > 1
     const int EL = 256 / SPL;
     const int e = threadIdx.x % EL, sp = threadIdx.x / EL;
     const int T = d.TH * d.TW;
-    const int64_t total = (int64_t)d.NP * d.NQ;
+    const int ngrp = (d.NQ + VC - 1) / VC;
+    const int64_t total = (int64_t)d.NP * ngrp;
     const int64_t idx = (int64_t)blockIdx.x * EL + e;
     const bool ok = idx < total;
-    const int cqi = ok ? (int)(idx % d.NQ) : 0;
-    const int np = ok ? (int)(idx / d.NQ) : 0;
+    const int cq0 = ok ? (int)(idx % ngrp) * VC : 0;
+    const int np = ok ? (int)(idx / ngrp) : 0;
     const int64_t slab_stride = (int64_t)NPpad * ldk;
-    const float* src = d.ws + (int64_t)np * ldk + cqi;
-    float* dst = d.dW + (int64_t)np * d.s_np + (int64_t)cqi * d.s_cq;
+    const float* src = d.ws + (int64_t)np * ldk + cq0;
     for (int t0 = 0; t0 < T; t0 += TT) {
-        float s[TT];
+        float s[TT][VC];
 #pragma unroll
-        for (int j = 0; j < TT; ++j) s[j] = 0.f;
+        for (int j = 0; j < TT; ++j)
+#pragma unroll
+            for (int v = 0; v < VC; ++v) s[j][v] = 0.f;
         if (ok) {
             for (int k = sp; k < nsplit; k += SPL) {
 #pragma unroll
                 for (int j = 0; j < TT; ++j)
-                    if (t0 + j < T) s[j] += src[k * slab_stride + (int64_t)(t0 + j) * d.QC];
+                    if (t0 + j < T) {
+                        const float* q = src + k * slab_stride + (int64_t)(t0 + j) * d.QC;
+                        if (VC == 4) {
+                            const float4 x = *reinterpret_cast<const float4*>(q);
+                            s[j][0] += x.x; s[j][1 % VC] += x.y; s[j][2 % VC] += x.z; s[j][3 % VC] += x.w;
+                        } else {
+                            s[j][0] += q[0];
+                        }
+                    }
             }
         }
-        if (SPL > 1) {
+        if (SPL == 1) {
+            if (ok) {
 #pragma unroll
-            for (int j = 0; j < TT; ++j) {
-                __syncthreads();
-                red[threadIdx.x] = s[j];
-                __syncthreads();
-                if (sp == 0) for (int k = 1; k < SPL; ++k) s[j] += red[k * EL + e];
-            }
-        }
-        if (ok && sp == 0) {
+                for (int v = 0; v < VC; ++v) {
+                    if (cq0 + v >= d.NQ) continue;
+                    float* dst = d.dW + (int64_t)np * d.s_np + (int64_t)(cq0 + v) * d.s_cq;
 #pragma unroll
-            for (int j = 0; j < TT; ++j)
-                if (t0 + j < T) {
-                    float* q = dst + (int64_t)(t0 + j) * d.s_t;
-                    *q = d.accumulate ? (*q + s[j]) : s[j];
+                    for (int j = 0; j < TT; ++j)
+                        if (t0 + j < T) {
+                            float* q = dst + (int64_t)(t0 + j) * d.s_t;
+                            *q = d.accumulate ? (*q + s[j][v]) : s[j][v];
+                        }
                 }
+            }
+            continue;
+        }
+        // all partials -> LDS once; then every thread adds the SPL partials of a few outputs in fixed order,
+        // consecutive threads taking consecutive taps of one weight row (contiguous runs in OIHW)
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TT; ++j)
+#pragma unroll
+            for (int v = 0; v < VC; ++v) red[((sp * EL + e) * VC + v) * TT + j] = s[j][v];
+        __syncthreads();
+        const int nout = EL * VC * TT;
+        for (int q = threadIdx.x; q < nout; q += 256) {
+            const int j = q % TT, ev = q / TT;
+            const int ee = ev / VC, v = ev - ee * VC;
+            const int64_t oidx = (int64_t)blockIdx.x * EL + ee;
+            if (oidx >= total || t0 + j >= T) continue;
+            const int ocq = (int)(oidx % ngrp) * VC + v;
+            if (ocq >= d.NQ) continue;
+            const int onp = (int)(oidx / ngrp);
+            float acc = 0.f;
+            for (int k = 0; k < SPL; ++k) acc += red[(k * EL * VC + ev) * TT + j];
+            float* dst = d.dW + (int64_t)onp * d.s_np + (int64_t)ocq * d.s_cq + (int64_t)(t0 + j) * d.s_t;
+            *dst = d.accumulate ? (*dst + acc) : acc;
         }
     }
 }
@@ -404,13 +436,19 @@ extern "C" int vg_wgrad(const vg_wg_desc* d, int dtype, void* stream) {
         hipLaunchKernelGGL(wgrad_bf16_kernel, grid, dim3(256), 0, s, *d, p.rows_per_split, p.KQ, p.NPpad);
     rc = VG_LAUNCH_RC();
     if (rc) return rc;
-    const int64_t total = (int64_t)d->NP * d->NQ;
+    const bool vec = (d->NQ % 4 == 0) && (d->QC % 4 == 0);
+    const int VC = vec ? 4 : 1;
+    const int64_t total = (int64_t)d->NP * ((d->NQ + VC - 1) / VC);
     const int SPL = p.nsplit >= 64 ? 32 : (p.nsplit >= 8 ? 8 : 1);
     const int EL = 256 / SPL;
     const dim3 rgrid((unsigned)((total + EL - 1) / EL));
-    if (d->TH * d->TW >= 16)
-        hipLaunchKernelGGL(wgrad_reduce_kernel<16>, rgrid, dim3(256), 0, s, *d, p.nsplit, p.NPpad, p.tiles_kq * p.tile, SPL);
-    else
-        hipLaunchKernelGGL(wgrad_reduce_kernel<4>, rgrid, dim3(256), 0, s, *d, p.nsplit, p.NPpad, p.tiles_kq * p.tile, SPL);
+    const int ldk = p.tiles_kq * p.tile;
+    const bool big = d->TH * d->TW >= 16;
+    const int TTv = big ? 16 : 4;
+    const size_t shm = SPL > 1 ? (size_t)256 * VC * TTv * sizeof(float) : 0;      // <= 64 KB
+    if (vec && big) hipLaunchKernelGGL((wgrad_reduce_kernel<16, 4>), rgrid, dim3(256), shm, s, *d, p.nsplit, p.NPpad, ldk, SPL);
+    else if (vec) hipLaunchKernelGGL((wgrad_reduce_kernel<4, 4>), rgrid, dim3(256), shm, s, *d, p.nsplit, p.NPpad, ldk, SPL);
+    else if (big) hipLaunchKernelGGL((wgrad_reduce_kernel<16, 1>), rgrid, dim3(256), shm, s, *d, p.nsplit, p.NPpad, ldk, SPL);
+    else hipLaunchKernelGGL((wgrad_reduce_kernel<4, 1>), rgrid, dim3(256), shm, s, *d, p.nsplit, p.NPpad, ldk, SPL);
     return VG_LAUNCH_RC();
 }

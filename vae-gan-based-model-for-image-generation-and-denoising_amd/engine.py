@@ -101,6 +101,7 @@ class StackEngine:
         self._specs: Dict = {}
         self._packs: Optional[Dict] = None
         self._pack_key = None
+        self._pack_ptrs = None
         self.pending_bn_ticks = 0           # num_batches_tracked increments not yet applied (flushed lazily)
 
     # ---- geometry (cached per batch size) -----------------------------------------------------
@@ -142,23 +143,41 @@ class StackEngine:
         key = (_weights_epoch[0], tuple(p._version for p in self.params()), self.stages[0].conv.weight.data_ptr())
         if self._packs is not None and key == self._pack_key:
             return self._packs
-        packs = self._packs if self._packs is not None else {}
+        ptr_key = tuple(p.data_ptr() for p in self.params())
+        if self._packs is None or self._pack_ptrs != ptr_key:
+            self._build_pack_table(ptr_key)
+        packs = self._packs
+        for i, st in enumerate(self.stages):
+            ent = packs[i]
+            if st.kind == "linear2":
+                torch.cat([st.conv.weight.detach(), st.conv2.weight.detach()], 0, out=ent["wcat"])
+                torch.cat([st.conv.bias.detach(), st.conv2.bias.detach()], 0, out=ent["bias"])
+            else:
+                ent["bias"] = st.conv.bias.detach() if st.has_bias else None
+        ops.pack_weights_multi(self._pack_table, self._pack_n, self._pack_max, self.dtype)
+        self._pack_key = key
+        return packs
+
+    def _build_pack_table(self, ptr_key) -> None:
+        """(Re)allocate the packed operand buffers and the device-side descriptor table (pointers are stable while
+        the parameters stay where they are, i.e. after the optimizer re-homed them into its flat buffer)."""
+        packs, descs, mx = {}, [], 1
+        dev = self.stages[0].conv.weight.device
         for i, st in enumerate(self.stages):
             ent = packs.setdefault(i, {})
             if st.kind == "linear2":
-                w = torch.cat([st.conv.weight.detach(), st.conv2.weight.detach()], 0)
-                ent["wcat"] = w
+                ent["wcat"] = torch.cat([st.conv.weight.detach(), st.conv2.weight.detach()], 0)
                 ent["bias"] = torch.cat([st.conv.bias.detach(), st.conv2.bias.detach()], 0)
+                w = ent["wcat"]
             else:
                 w = st.conv.weight.detach()
-                ent["bias"] = st.conv.bias.detach() if st.has_bias else None
-            _, pk = self.spec(i, 1, "fprop") if st.kind != "head" else self.spec(i, 1, "fprop")
-            ent["fprop"] = ops.pack_weights(pk, w, self.dtype, out=ent.get("fprop"))
-            if st.kind != "head":
-                _, pkd = self.spec(i, 1, "dgrad")
-                ent["dgrad"] = ops.pack_weights(pkd, w, self.dtype, out=ent.get("dgrad"))
-        self._packs, self._pack_key = packs, key
-        return packs
+            for what in (("fprop",) if st.kind == "head" else ("fprop", "dgrad")):
+                _, pk = self.spec(i, 1, what)
+                ent[what] = torch.empty(pk.numel(), dtype=ops.TORCH_DT[self.dtype], device=dev)
+                descs.append(ops.pack_desc(pk, w, ent[what]))
+                mx = max(mx, pk.numel())
+        self._packs, self._pack_ptrs = packs, ptr_key
+        self._pack_table, self._pack_n, self._pack_max = ops.pack_table(descs, dev), len(descs), mx
 
     def flush_bn_ticks(self) -> None:
         if self.pending_bn_ticks:

@@ -103,7 +103,7 @@ def _direct(B, H, W, C, N, k, s, p, dtype, s_n, s_c) -> Tuple[GGSpec, PackSpec]:
                 y0=[-p], x0=[-p], N=N, Kp=Kp, OH=OH, OW=OW, OC=padc(N, dtype), OSY=1, OSX=1,
                 ooy=[0], oox=[0], nphase=1)
     pk = PackSpec(nphase=1, N=N, C=C, IC=IC, TH=k, TW=k, Kp=Kp, s_n=s_n, s_c=s_c, KW=k,
-                  kh0=[0], kw0=[0], kh_step=1, kw_step=1)
+                  kh0=[0], kw0=[0], kh_step=1, kw_step=1, KHW=k * k)
     return gg, pk
 
 
@@ -120,7 +120,7 @@ def _transposed(B, h, w, C, BH, BW, N, k, s, p, dtype, s_n, s_c) -> Tuple[GGSpec
                     y0=[p], x0=[p], N=N, Kp=Kp, OH=BH, OW=BW, OC=padc(N, dtype), OSY=1, OSX=1,
                     ooy=[0], oox=[0], nphase=1)
         pk = PackSpec(nphase=1, N=N, C=C, IC=IC, TH=k, TW=k, Kp=Kp, s_n=s_n, s_c=s_c, KW=k,
-                      kh0=[0], kw0=[0], kh_step=1, kw_step=1)
+                      kh0=[0], kw0=[0], kh_step=1, kw_step=1, KHW=k * k)
         return gg, pk
     if s != 2 or k % 2 != 0:
         raise NotImplementedError(f"transposed geometry supports stride 1, or stride 2 with even k (got k={k}, s={s})")
@@ -139,7 +139,7 @@ def _transposed(B, h, w, C, BH, BW, N, k, s, p, dtype, s_n, s_c) -> Tuple[GGSpec
                 TH=T, TW=T, y0=y0, x0=x0, N=N, Kp=Kp, OH=BH, OW=BW, OC=padc(N, dtype), OSY=2, OSX=2,
                 ooy=ooy, oox=oox, nphase=4)
     pk = PackSpec(nphase=4, N=N, C=C, IC=IC, TH=T, TW=T, Kp=Kp, s_n=s_n, s_c=s_c, KW=k,
-                  kh0=kh0, kw0=kw0, kh_step=2, kw_step=2)
+                  kh0=kh0, kw0=kw0, kh_step=2, kw_step=2, KHW=k * k)
     return gg, pk
 
 

@@ -98,6 +98,25 @@ def pack_weights(pk: PackSpec, w: torch.Tensor, dtype: int, out: torch.Tensor = 
     return out
 
 
+def pack_desc(pk: PackSpec, w: torch.Tensor, out: torch.Tensor) -> L.PackDesc:
+    return L.PackDesc(src=w.data_ptr(), dst=out.data_ptr(), nphase=pk.nphase, N=pk.N, C=pk.C, IC=pk.IC, TH=pk.TH,
+                      TW=pk.TW, Kp=pk.Kp, s_n=pk.s_n, s_c=pk.s_c, KW=pk.KW, kh0=L.i4(pk.kh0), kw0=L.i4(pk.kw0),
+                      kh_step=pk.kh_step, kw_step=pk.kw_step, tap_in_n=pk.tap_in_n, KHW=pk.KHW)
+
+
+def pack_table(descs, device) -> torch.Tensor:
+    """Descriptor table in device memory for pack_weights_multi (built once per network)."""
+    import ctypes
+    arr = (L.PackDesc * len(descs))(*descs)
+    raw = bytes(ctypes.string_at(ctypes.addressof(arr), ctypes.sizeof(arr)))
+    return torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+
+
+def pack_weights_multi(table: torch.Tensor, n: int, max_elems: int, dtype: int) -> None:
+    L.check(L.load().vg_pack_weights_multi(table.data_ptr(), n, max_elems, dtype, L.stream_ptr()),
+            "vg_pack_weights_multi")
+
+
 def _gg_desc(g: GGSpec, X, Wp, Y, bias, stats, cap) -> L.GGDesc:
     return L.GGDesc(X=X.data_ptr(), W=Wp.data_ptr(), Y=Y.data_ptr(),
                     bias=0 if bias is None else bias.data_ptr(), stats=0 if stats is None else stats.data_ptr(),
