@@ -61,55 +61,85 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const vg_pack_desc* __r
         const int c0 = ct * PK_CT, n0 = nt * PK_NT, tap0 = tt * PK_TT;
         const int ntap = min(PK_TT, d.KHW - tap0);
         __syncthreads();
-        // ---- load: order the (n, c, tap) enumeration so consecutive threads walk the source contiguously ----
-        const int cnt = PK_NT * PK_CT * ntap;
-        for (int e = threadIdx.x; e < cnt; e += 256) {
-            int nn, cc, tp;
-            tp = e % ntap;
-            const int r = e / ntap;
-            if (d.s_c <= d.s_n) { cc = r % PK_CT; nn = r / PK_CT; }       // [n][c][tap] source (c stride = taps)
-            else { nn = r % PK_NT; cc = r / PK_NT; }                      // [c][n][tap] source (n stride = taps)
-            const int n = n0 + nn, c = c0 + cc;
-            float v = 0.f;
-            if (n < rowsN && c < d.C) v = d.src[(int64_t)n * d.s_n + (int64_t)c * d.s_c + tap0 + tp];
-            tile[nn][cc][tp] = v;
+        // ---- load (division-free for power-of-two tap counts): consecutive lanes walk the source contiguously ----
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const bool pow2 = (ntap & (ntap - 1)) == 0;
+        const int sh = 31 - __builtin_clz(ntap);
+        if (d.s_c <= d.s_n) {
+            // [n][c][tap] source: for a fixed n the (c, tap) block is one contiguous run -> wave = n row
+            const int n = n0 + wave;
+            for (int e = lane; e < PK_CT * ntap; e += 64) {
+                const int cc = pow2 ? (e >> sh) : (e / ntap);
+                const int tp = pow2 ? (e & (ntap - 1)) : (e - cc * ntap);
+                const int c = c0 + cc;
+                float v = 0.f;
+                if (n < rowsN && c < d.C) v = d.src[(int64_t)n * d.s_n + (int64_t)c * d.s_c + tap0 + tp];
+                tile[wave][cc][tp] = v;
+            }
+        } else {
+            // [c][n][tap] source: for a fixed c the (n, tap) block of the 4 rows is contiguous -> lanes = (n, tap)
+            const int per_c = PK_NT * ntap;
+            for (int cc = wave; cc < PK_CT; cc += 4) {
+                const int c = c0 + cc;
+                for (int e = lane; e < per_c; e += 64) {
+                    const int nn = pow2 ? (e >> sh) : (e / ntap);
+                    const int tp = pow2 ? (e & (ntap - 1)) : (e - nn * ntap);
+                    const int n = n0 + nn;
+                    float v = 0.f;
+                    if (n < rowsN && c < d.C) v = d.src[(int64_t)n * d.s_n + (int64_t)c * d.s_c + tap0 + tp];
+                    tile[nn][cc][tp] = v;
+                }
+            }
         }
         __syncthreads();
-        // ---- store: channel index fastest ----
-        if (d.tap_in_n) {
-            // dst[(tap*CO + co)][ci]: one K-major row per (tap, co)
-            const int cnt2 = PK_NT * ntap * PK_CT;
-            for (int e = threadIdx.x; e < cnt2; e += 256) {
-                const int cc = e % PK_CT;
-                const int r = e / PK_CT;
-                const int tp = r % ntap, nn = r / ntap;
-                const int n = n0 + nn, c = c0 + cc;
-                if (n < rowsN && c < d.Kp)
-                    store1<DT>(d.dst, ((int64_t)(tap0 + tp) * rowsN + n) * d.Kp + c, c < d.IC ? tile[nn][cc][tp] : 0.f);
-            }
-            // K padding beyond the last channel tile
-            if (ct == ctiles - 1)
-                for (int e = threadIdx.x; e < PK_NT * ntap * (d.Kp - ctiles * PK_CT); e += 256) {
-                    const int w = d.Kp - ctiles * PK_CT;
-                    const int c = ctiles * PK_CT + e % w;
-                    const int r = e / w;
-                    const int tp = r % ntap, n = n0 + r / ntap;
-                    if (n < rowsN) store1<DT>(d.dst, ((int64_t)(tap0 + tp) * rowsN + n) * d.Kp + c, 0.f);
-                }
-            continue;
-        }
-        const int cnt2 = d.nphase * PK_NT * T * PK_CT;
-        for (int e = threadIdx.x; e < cnt2; e += 256) {
-            const int cc = e % PK_CT;
-            int r = e / PK_CT;
-            const int t = r % T; r /= T;
-            const int nn = r % PK_NT;
-            const int p = r / PK_NT;
-            const int a = t / d.TW, b = t - a * d.TW;
-            const int ft = (d.kh0[p] + d.kh_step * a) * d.KW + d.kw0[p] + d.kw_step * b - tap0;
+        // ---- store: wave = n row of the tile, lane = channel (128-byte runs), loops over phases and taps ----
+        {
+            const int nn = wave, cc = lane;
             const int n = n0 + nn, c = c0 + cc;
-            if (ft >= 0 && ft < ntap && n < d.N && c < d.IC)
-                store1<DT>(d.dst, ((int64_t)p * d.N + n) * d.Kp + (int64_t)t * d.IC + c, tile[nn][cc][ft]);
+            if (d.tap_in_n) {
+                // dst[(tap*CO + co)][ci]: one K-major row per (tap, co)
+                if (n < rowsN) {
+                    for (int tp = 0; tp < ntap; ++tp) {
+                        const int64_t row = ((int64_t)(tap0 + tp) * rowsN + n) * d.Kp;
+                        if (c < d.Kp) store1<DT>(d.dst, row + c, c < d.IC ? tile[nn][cc][tp] : 0.f);
+                        if (ct == ctiles - 1)
+                            for (int k = ctiles * PK_CT + lane; k < d.Kp; k += 64) store1<DT>(d.dst, row + k, 0.f);
+                    }
+                }
+                continue;
+            }
+            // 16-byte stores: a lane owns VE consecutive channels, LPR lanes cover the 64-channel run of one
+            // (phase, tap) row and the wave walks 64/LPR rows per instruction (IC is a multiple of VE by contract)
+            constexpr int VE = 16 / ElemT<DT>::size;             // 4 (f32) / 8 (bf16)
+            constexpr int LPR = PK_CT / VE;                      // 16 / 8 lanes per row run
+            constexpr int RPI = 64 / LPR;                        // 4 / 8 rows per wave instruction
+            const int sub = lane / LPR, cv = (lane % LPR) * VE;
+            const int cbase = c0 + cv;
+            if (n < d.N && cbase < d.IC) {
+                const int rows = d.nphase * T;
+                for (int r0 = 0; r0 < rows; r0 += RPI) {
+                    const int r = r0 + sub;
+                    if (r >= rows) break;
+                    const int p = r / T, t = r - p * T;
+                    const int a = t / d.TW, b = t - a * d.TW;
+                    const int ft = (d.kh0[p] + d.kh_step * a) * d.KW + d.kw0[p] + d.kw_step * b - tap0;
+                    if (ft < 0 || ft >= ntap) continue;
+                    typename ElemT<DT>::type* q = reinterpret_cast<typename ElemT<DT>::type*>(d.dst) +
+                                                  ((int64_t)p * d.N + n) * d.Kp + (int64_t)t * d.IC + cbase;
+                    if constexpr (DT == VG_F32) {
+                        float4 v = {tile[nn][cv][ft], tile[nn][cv + 1][ft], tile[nn][cv + 2][ft], tile[nn][cv + 3][ft]};
+                        *reinterpret_cast<float4*>(q) = v;
+                    } else {
+                        u32x4 v;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            v[k] = (uint32_t)ElemT<VG_BF16>::from_f32(tile[nn][cv + 2 * k][ft]) |
+                                   ((uint32_t)ElemT<VG_BF16>::from_f32(tile[nn][cv + 2 * k + 1][ft]) << 16);
+                        *reinterpret_cast<u32x4*>(q) = v;
+                    }
+                }
+            }
+            (void)c; (void)cc;
         }
         // K padding [T*IC, Kp) of the rows of this n tile (written once, by the first channel/tap tile)
         if (ct == 0 && tt == 0) {

@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const vg_wg_desc d, int
 // per-element loop is a serial chain of HBM latencies, so the slabs are walked by SPL lanes, combined via LDS.
 template <int TT, int VC>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const vg_wg_desc d, int nsplit, int NPpad, int ldk, int SPL) {
-    extern __shared__ __attribute__((aligned(16))) float red[];      // [SPL][EL*VC][TT] when SPL > 1
+    extern __shared__ __attribute__((aligned(16))) float red[];      // [SPL][EL*VC][TT]
     const int EL = 256 / SPL;
     const int e = threadIdx.x % EL, sp = threadIdx.x / EL;
     const int T = d.TH * d.TW;
@@ -316,7 +316,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const vg_wg_desc d, i
     const int np = ok ? (int)(idx / ngrp) : 0;
     const int64_t slab_stride = (int64_t)NPpad * ldk;
     const float* src = d.ws + (int64_t)np * ldk + cq0;
-    for (int t0 = 0; t0 < T; t0 += TT) {
+    {
+        const int t0 = blockIdx.y * TT;                 // tap groups run in parallel (more blocks, shorter chains)
         float s[TT][VC];
 #pragma unroll
         for (int j = 0; j < TT; ++j)
@@ -336,22 +337,6 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const vg_wg_desc d, i
                         }
                     }
             }
-        }
-        if (SPL == 1) {
-            if (ok) {
-#pragma unroll
-                for (int v = 0; v < VC; ++v) {
-                    if (cq0 + v >= d.NQ) continue;
-                    float* dst = d.dW + (int64_t)np * d.s_np + (int64_t)(cq0 + v) * d.s_cq;
-#pragma unroll
-                    for (int j = 0; j < TT; ++j)
-                        if (t0 + j < T) {
-                            float* q = dst + (int64_t)(t0 + j) * d.s_t;
-                            *q = d.accumulate ? (*q + s[j][v]) : s[j][v];
-                        }
-                }
-            }
-            continue;
         }
         // all partials -> LDS once; then every thread adds the SPL partials of a few outputs in fixed order,
         // consecutive threads taking consecutive taps of one weight row (contiguous runs in OIHW)
@@ -441,11 +426,13 @@ extern "C" int vg_wgrad(const vg_wg_desc* d, int dtype, void* stream) {
     const int64_t total = (int64_t)d->NP * ((d->NQ + VC - 1) / VC);
     const int SPL = p.nsplit >= 64 ? 32 : (p.nsplit >= 8 ? 8 : 1);
     const int EL = 256 / SPL;
-    const dim3 rgrid((unsigned)((total + EL - 1) / EL));
     const int ldk = p.tiles_kq * p.tile;
-    const bool big = d->TH * d->TW >= 16;
+    const int Ttaps = d->TH * d->TW;
+    // 16 taps per thread only when there is plenty of parallelism anyway; otherwise 4 (tap groups -> blockIdx.y)
+    const bool big = Ttaps >= 16 && (total + EL - 1) / EL >= 2048;
     const int TTv = big ? 16 : 4;
-    const size_t shm = SPL > 1 ? (size_t)256 * VC * TTv * sizeof(float) : 0;      // <= 64 KB
+    const dim3 rgrid((unsigned)((total + EL - 1) / EL), (unsigned)((Ttaps + TTv - 1) / TTv));
+    const size_t shm = (size_t)256 * VC * TTv * sizeof(float);                    // <= 64 KB
     if (vec && big) hipLaunchKernelGGL((wgrad_reduce_kernel<16, 4>), rgrid, dim3(256), shm, s, *d, p.nsplit, p.NPpad, ldk, SPL);
     else if (vec) hipLaunchKernelGGL((wgrad_reduce_kernel<4, 4>), rgrid, dim3(256), shm, s, *d, p.nsplit, p.NPpad, ldk, SPL);
     else if (big) hipLaunchKernelGGL((wgrad_reduce_kernel<16, 1>), rgrid, dim3(256), shm, s, *d, p.nsplit, p.NPpad, ldk, SPL);

@@ -24,12 +24,11 @@ from ._lib import VG_ACT_LRELU, VG_ACT_NONE, VG_ACT_RELU
 
 BN_MOMENTUM, BN_EPS = 0.1, 1e-5       # nn.BatchNorm2d defaults (main_vae.py:24, gan_code.py:22)
 
-# bumped by every optimizer step (optim.Adam.step); packed operand copies older than this are stale
-_weights_epoch = [0]
-
-
-def bump_weights_epoch() -> None:
-    _weights_epoch[0] += 1
+def bump_weights_epoch(params) -> None:
+    """Called by optim.Adam after it rewrote `params` behind torch's back (raw-pointer kernel): packed operand
+    copies of exactly these parameters become stale (a global counter would re-pack E and G every time D steps)."""
+    for p in params:
+        p._vg_epoch = getattr(p, "_vg_epoch", 0) + 1
 
 
 @dataclass
@@ -140,7 +139,8 @@ class StackEngine:
         self._pack_key = None
 
     def _ensure_packed(self) -> Dict:
-        key = (_weights_epoch[0], tuple(p._version for p in self.params()), self.stages[0].conv.weight.data_ptr())
+        key = (tuple((getattr(p, "_vg_epoch", 0), p._version) for p in self.params()),
+               self.stages[0].conv.weight.data_ptr())
         if self._packs is not None and key == self._pack_key:
             return self._packs
         ptr_key = tuple(p.data_ptr() for p in self.params())

@@ -56,7 +56,7 @@ class Adam:
                 p._vg_fresh = True
         self.grad_scale = 1.0                                   # 1/world_size under data parallelism
         self.steps = 0
-        bump_weights_epoch()
+        bump_weights_epoch(self.params)
 
     # -- torch.optim.Optimizer surface ---------------------------------------------------------------
     @property
@@ -88,7 +88,7 @@ class Adam:
         ops.adam_step(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0], self.betas[1],
                       self.eps, self.grad_scale, self.state_dev)
         self.steps += 1
-        bump_weights_epoch()
+        bump_weights_epoch(self.params)
 
     def state_dict(self):
         st = {}
