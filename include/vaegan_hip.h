@@ -78,6 +78,8 @@ typedef struct vg_gg_desc {
 
 /* Number of stats slabs vg_gather_gemm will write for this descriptor (host-only query). */
 int vg_gather_gemm_nparts(const vg_gg_desc* d, int dtype);
+/* Rows (M) covered by one statistics slab = the M edge of the tile the launcher picks (host-only query). */
+int vg_gather_gemm_tile_m(const vg_gg_desc* d, int dtype);
 int vg_gather_gemm(const vg_gg_desc* d, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -140,28 +142,34 @@ int vg_bn_finalize(const float* stats, int nparts, int C, int64_t count,
 int vg_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
                       const float* running_var, float eps, int C,
                       float* scale, float* shift, void* stream);
-/* y = act(scale[c]*x + shift[c]); scale/shift NULL -> pure activation. */
+/* y = act(scale[c]*x + shift[c]); scale/shift NULL -> pure activation.
+ * groups > 1: the rows are `groups` equal, independent row blocks (e.g. the real and the fake batch of one
+ * Discriminator iteration, vaegan_code.py:96-97, run as one launch) with their own coefficient sets:
+ * group g reads scale[g*gstride + c] (same for shift / mean / invstd below). */
 int vg_bn_act_forward(const void* x, void* y, const float* scale, const float* shift,
-                      int64_t rows, int C, int act, float slope, int dtype, void* stream);
+                      int64_t rows, int C, int act, float slope, int groups, int64_t gstride,
+                      int dtype, void* stream);
 /* Standalone per-channel statistics of an NHWC tensor (used when no conv epilogue produced them). */
 int vg_channel_stats(const void* x, int64_t rows, int C, float* stats, int stats_capacity,
                      int* nparts_out, int dtype, void* stream);
-/* Backward pass 1: dz = dy_act * act'(z), z = scale*x+shift; partial sums of dz and dz*xhat. */
+/* Backward pass 1: dz = dy_act * act'(z), z = scale*x+shift; partial sums of dz and dz*xhat.
+ * With groups > 1 the slabs of group g are parts [g*nparts_out, (g+1)*nparts_out). */
 int vg_bn_act_backward_reduce(const void* x, const void* dy, const float* scale, const float* shift,
                               const float* mean, const float* invstd,
                               int64_t rows, int C, int act, float slope,
                               float* partial, int partial_capacity, int* nparts_out,
-                              int dtype, void* stream);
+                              int groups, int64_t gstride, int dtype, void* stream);
 /* Backward finalize: dgamma, dbeta (accumulate optional) and the two per-channel coefficients. */
 int vg_bn_backward_finalize(const float* partial, int nparts, int C, int64_t count,
                             const float* gamma, const float* invstd,
                             float* dgamma, float* dbeta, int accumulate,
                             float* coef /* [3][C]: a, b, c */, void* stream);
-/* Backward pass 2: dx = a[c]*dz - b[c]*xhat - c[c]   (dz recomputed from dy, x). */
+/* Backward pass 2: dx = a[c]*dz - b[c]*xhat - c[c]   (dz recomputed from dy, x); group g uses coef + g*cstride. */
 int vg_bn_act_backward_apply(const void* x, const void* dy, void* dx,
                              const float* scale, const float* shift,
                              const float* mean, const float* invstd, const float* coef,
-                             int64_t rows, int C, int act, float slope, int dtype, void* stream);
+                             int64_t rows, int C, int act, float slope, int groups, int64_t gstride,
+                             int64_t cstride, int dtype, void* stream);
 /* Activation-only backward (first Discriminator layer has no BN, gan_code.py:61-62). */
 int vg_act_backward(const void* x, const void* dy, void* dx, int64_t n, int act, float slope,
                     int dtype, void* stream);

@@ -241,6 +241,27 @@ def test_step_is_bitwise_deterministic():
         assert torch.equal(a, b)
 
 
+def test_grouped_discriminator_pass_equals_separate_passes():
+    """One grouped 2B-row pass per D iteration (per-group BatchNorm statistics) vs the reference's two calls."""
+    outs = []
+    for grouped in (True, False):
+        e, g, d, tr = build(64)
+        tr.group_d_passes = grouped
+        real, ez, er, ec = (t.to(DEV) for t in make_inputs(8, 64, 4321))
+        l = tr.train_step(real, 60, ez, er, ec)
+        assert d._engine.can_group(8, 2, real) is True
+        outs.append((l[:5].cpu().clone(), {k: v.cpu().clone() for k, v in d.state_dict().items()},
+                     tr.opt_D.exp_avg.cpu().clone(), tr.opt_G.exp_avg.cpu().clone()))
+    torch.testing.assert_close(outs[0][0], outs[1][0], rtol=2e-4, atol=1e-6)   # adv loss sits behind 2 Adam steps of D
+    for k, v in outs[0][1].items():
+        if k.endswith("num_batches_tracked"):
+            assert int(v) == int(outs[1][1][k]) == 5
+        elif "running" in k:
+            torch.testing.assert_close(v, outs[1][1][k], rtol=1e-4, atol=1e-6, msg=k)
+    for a, b in ((outs[0][2], outs[1][2]), (outs[0][3], outs[1][3])):          # Adam first moments = 0.1 * grads
+        assert float((a - b).abs().max() / b.abs().max()) < 2e-3
+
+
 def test_graph_replay_is_bitwise_identical_to_eager():
     """train_step_graphed (eager warm-up, capture, replays) == train_step, bit for bit, incl. BN counters."""
     res = []

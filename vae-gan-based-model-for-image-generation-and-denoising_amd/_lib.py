@@ -62,6 +62,7 @@ SIGNATURES = {
     "vg_abi_version": (c_int, []),
     "vg_build_info": (c_char_p, []),
     "vg_gather_gemm_nparts": (c_int, [POINTER(GGDesc), _I]),
+    "vg_gather_gemm_tile_m": (c_int, [POINTER(GGDesc), _I]),
     "vg_gather_gemm": (c_int, [POINTER(GGDesc), _I, _P]),
     "vg_wgrad_ws_bytes": (c_int64, [POINTER(WGDesc), _I]),
     "vg_wgrad": (c_int, [POINTER(WGDesc), _I, _P]),
@@ -69,11 +70,12 @@ SIGNATURES = {
     "vg_pack_weights_multi": (c_int, [_P, _I, _L, _I, _P]),
     "vg_bn_finalize": (c_int, [_P, _I, _I, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
     "vg_bn_eval_coeffs": (c_int, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),
-    "vg_bn_act_forward": (c_int, [_P, _P, _P, _P, _L, _I, _I, _F, _I, _P]),
+    "vg_bn_act_forward": (c_int, [_P, _P, _P, _P, _L, _I, _I, _F, _I, _L, _I, _P]),
     "vg_channel_stats": (c_int, [_P, _L, _I, _P, _I, POINTER(c_int), _I, _P]),
-    "vg_bn_act_backward_reduce": (c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _P, _I, POINTER(c_int), _I, _P]),
+    "vg_bn_act_backward_reduce": (c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _P, _I, POINTER(c_int), _I, _L,
+                                          _I, _P]),
     "vg_bn_backward_finalize": (c_int, [_P, _I, _I, _L, _P, _P, _P, _P, _I, _P, _P]),
-    "vg_bn_act_backward_apply": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _I, _P]),
+    "vg_bn_act_backward_apply": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _I, _L, _L, _I, _P]),
     "vg_act_backward": (c_int, [_P, _P, _P, _L, _I, _F, _I, _P]),
     "vg_bias_grad": (c_int, [_P, _L, _I, _I, _P, _I, _P, _I, _I, _P]),
     "vg_nchw_to_nhwc": (c_int, [_P, _P, _F, _P, _I, _I, _I, _I, _I, _I, _P]),

@@ -37,7 +37,8 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const void* __restrict_
                                                          const float* __restrict__ mean,
                                                          const float* __restrict__ invstd, int64_t rows, int C,
                                                          int act, float slope, float* __restrict__ partial,
-                                                         int rows_per_part) {
+                                                         int rows_per_part, int64_t rows_per_group,
+                                                         int parts_per_group, int64_t gstride) {
     __shared__ float4 red[2][256];
     const int cols = C >> 2;
     const int cb = blockIdx.y * 256;
@@ -47,15 +48,19 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const void* __restrict_
     const int tr = tid / ncol, tc = tid - tr * ncol;
     const bool active = tr < rpp;
     const int c4 = (cb + tc) * 4;
-    const int64_t r0 = (int64_t)blockIdx.x * rows_per_part;
-    const int64_t r1 = min(rows, r0 + (int64_t)rows_per_part);
+    // groups: independent row ranges with their own coefficient sets (two Discriminator passes in one launch)
+    const int grp = blockIdx.x / parts_per_group;
+    const int64_t gbase = (int64_t)grp * rows_per_group;
+    const int64_t r0 = gbase + (int64_t)(blockIdx.x - grp * parts_per_group) * rows_per_part;
+    const int64_t r1 = min(min(rows, gbase + rows_per_group), r0 + (int64_t)rows_per_part);
+    const int64_t go = (int64_t)grp * gstride;
     float4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
     if (active) {
         float4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f}, mu = sh, is = sc;
         if (MODE == 1) {
-            if (scale) { sc = *reinterpret_cast<const float4*>(scale + c4); sh = *reinterpret_cast<const float4*>(shift + c4); }
-            mu = *reinterpret_cast<const float4*>(mean + c4);
-            is = *reinterpret_cast<const float4*>(invstd + c4);
+            if (scale) { sc = *reinterpret_cast<const float4*>(scale + go + c4); sh = *reinterpret_cast<const float4*>(shift + go + c4); }
+            mu = *reinterpret_cast<const float4*>(mean + go + c4);
+            is = *reinterpret_cast<const float4*>(invstd + go + c4);
         }
         for (int64_t r = r0 + tr; r < r1; r += rpp) {
             const float4 v = load4<DT>(x, r * C + c4);
@@ -155,13 +160,15 @@ template <int DT>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const void* __restrict__ x, void* __restrict__ y,
                                                          const float* __restrict__ scale,
                                                          const float* __restrict__ shift, int64_t nvec, int cols,
-                                                         int act, float slope) {
+                                                         int act, float slope, int64_t nvec_per_group,
+                                                         int64_t gstride) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
         const int c4 = (int)(i % cols) * 4;
         float4 v = load4<DT>(x, i * 4);
         if (scale) {
-            const float4 sc = *reinterpret_cast<const float4*>(scale + c4);
-            const float4 sh = *reinterpret_cast<const float4*>(shift + c4);
+            const int64_t go = (i / nvec_per_group) * gstride;
+            const float4 sc = *reinterpret_cast<const float4*>(scale + go + c4);
+            const float4 sh = *reinterpret_cast<const float4*>(shift + go + c4);
             v.x = sc.x * v.x + sh.x; v.y = sc.y * v.y + sh.y; v.z = sc.z * v.z + sh.z; v.w = sc.w * v.w + sh.w;
         }
         v.x = act_fwd(v.x, act, slope); v.y = act_fwd(v.y, act, slope);
@@ -194,18 +201,22 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const void* __res
                                                                const float* __restrict__ mean,
                                                                const float* __restrict__ invstd,
                                                                const float* __restrict__ coef, int64_t nvec, int cols,
-                                                               int C, int act, float slope) {
+                                                               int C, int act, float slope, int64_t nvec_per_group,
+                                                               int64_t gstride, int64_t cstride) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
         const int c4 = (int)(i % cols) * 4;
         const float4 v = load4<DT>(x, i * 4);
         const float4 g = load4<DT>(dy, i * 4);
-        const float4 sc = *reinterpret_cast<const float4*>(scale + c4);
-        const float4 sh = *reinterpret_cast<const float4*>(shift + c4);
-        const float4 mu = *reinterpret_cast<const float4*>(mean + c4);
-        const float4 is = *reinterpret_cast<const float4*>(invstd + c4);
-        const float4 ca = *reinterpret_cast<const float4*>(coef + c4);
-        const float4 cbv = *reinterpret_cast<const float4*>(coef + C + c4);
-        const float4 cc = *reinterpret_cast<const float4*>(coef + 2 * C + c4);
+        const int64_t grp = i / nvec_per_group;
+        const int64_t go = grp * gstride;
+        const float* cf = coef + grp * cstride;
+        const float4 sc = *reinterpret_cast<const float4*>(scale + go + c4);
+        const float4 sh = *reinterpret_cast<const float4*>(shift + go + c4);
+        const float4 mu = *reinterpret_cast<const float4*>(mean + go + c4);
+        const float4 is = *reinterpret_cast<const float4*>(invstd + go + c4);
+        const float4 ca = *reinterpret_cast<const float4*>(cf + c4);
+        const float4 cbv = *reinterpret_cast<const float4*>(cf + C + c4);
+        const float4 cc = *reinterpret_cast<const float4*>(cf + 2 * C + c4);
         float4 o;
         o.x = ca.x * act_bwd(sc.x * v.x + sh.x, g.x, act, slope) - cbv.x * ((v.x - mu.x) * is.x) - cc.x;
         o.y = ca.y * act_bwd(sc.y * v.y + sh.y, g.y, act, slope) - cbv.y * ((v.y - mu.y) * is.y) - cc.y;
@@ -253,20 +264,23 @@ inline int check_rows_c(const void* x, int64_t rows, int C, int dtype) {
     return 0;
 }
 
+// groups > 1: `rows` = groups * rows_per_group; the slabs of group g are parts [g*nparts_out, (g+1)*nparts_out)
 template <int MODE>
 int launch_reduce(const void* x, const void* dy, const float* scale, const float* shift, const float* mean,
                   const float* invstd, int64_t rows, int C, int act, float slope, float* partial, int capacity,
-                  int* nparts_out, int dtype, hipStream_t s) {
-    RedPlan p = plan_reduce(rows, C);
+                  int* nparts_out, int dtype, hipStream_t s, int groups = 1, int64_t gstride = 0) {
+    VG_CHECK_ARG(groups >= 1 && rows % groups == 0, VG_EINVAL);
+    const int64_t rpg = rows / groups;
+    RedPlan p = plan_reduce(rpg, C);
     if (nparts_out) *nparts_out = p.nparts;
-    VG_CHECK_ARG(partial != nullptr && capacity >= p.nparts, VG_EINVAL);
-    dim3 grid(p.nparts, p.ncolblk);
+    VG_CHECK_ARG(partial != nullptr && capacity >= p.nparts * groups, VG_EINVAL);
+    dim3 grid(p.nparts * groups, p.ncolblk);
     if (dtype == VG_F32)
         hipLaunchKernelGGL((col_reduce_kernel<VG_F32, MODE>), grid, dim3(256), 0, s, x, dy, scale, shift, mean, invstd,
-                           rows, C, act, slope, partial, p.rows_per_part);
+                           rows, C, act, slope, partial, p.rows_per_part, rpg, p.nparts, gstride);
     else
         hipLaunchKernelGGL((col_reduce_kernel<VG_BF16, MODE>), grid, dim3(256), 0, s, x, dy, scale, shift, mean, invstd,
-                           rows, C, act, slope, partial, p.rows_per_part);
+                           rows, C, act, slope, partial, p.rows_per_part, rpg, p.nparts, gstride);
     return VG_LAUNCH_RC();
 }
 
@@ -293,17 +307,19 @@ extern "C" int vg_bn_eval_coeffs(const float* gamma, const float* beta, const fl
 }
 
 extern "C" int vg_bn_act_forward(const void* x, void* y, const float* scale, const float* shift, int64_t rows, int C,
-                                 int act, float slope, int dtype, void* stream) {
+                                 int act, float slope, int groups, int64_t gstride, int dtype, void* stream) {
     int rc = check_rows_c(x, rows, C, dtype);
     if (rc) return rc;
     VG_CHECK_ARG(y != nullptr && (scale == nullptr) == (shift == nullptr), VG_EINVAL);
+    VG_CHECK_ARG(groups >= 1 && rows % groups == 0, VG_EINVAL);
     const int64_t nvec = rows * C / 4;
+    const int64_t nvg = nvec / groups;
     if (dtype == VG_F32)
         hipLaunchKernelGGL(bn_act_fwd_kernel<VG_F32>, dim3(ew_blocks(nvec)), dim3(256), 0, vg_stream(stream), x, y,
-                           scale, shift, nvec, C / 4, act, slope);
+                           scale, shift, nvec, C / 4, act, slope, nvg, gstride);
     else
         hipLaunchKernelGGL(bn_act_fwd_kernel<VG_BF16>, dim3(ew_blocks(nvec)), dim3(256), 0, vg_stream(stream), x, y,
-                           scale, shift, nvec, C / 4, act, slope);
+                           scale, shift, nvec, C / 4, act, slope, nvg, gstride);
     return VG_LAUNCH_RC();
 }
 
@@ -318,12 +334,12 @@ extern "C" int vg_channel_stats(const void* x, int64_t rows, int C, float* stats
 extern "C" int vg_bn_act_backward_reduce(const void* x, const void* dy, const float* scale, const float* shift,
                                          const float* mean, const float* invstd, int64_t rows, int C, int act,
                                          float slope, float* partial, int partial_capacity, int* nparts_out,
-                                         int dtype, void* stream) {
+                                         int groups, int64_t gstride, int dtype, void* stream) {
     int rc = check_rows_c(x, rows, C, dtype);
     if (rc) return rc;
     VG_CHECK_ARG(dy && scale && shift && mean && invstd, VG_EINVAL);
     return launch_reduce<1>(x, dy, scale, shift, mean, invstd, rows, C, act, slope, partial, partial_capacity,
-                            nparts_out, dtype, vg_stream(stream));
+                            nparts_out, dtype, vg_stream(stream), groups, gstride);
 }
 
 extern "C" int vg_bn_backward_finalize(const float* partial, int nparts, int C, int64_t count, const float* gamma,
@@ -337,17 +353,20 @@ extern "C" int vg_bn_backward_finalize(const float* partial, int nparts, int C, 
 
 extern "C" int vg_bn_act_backward_apply(const void* x, const void* dy, void* dx, const float* scale,
                                         const float* shift, const float* mean, const float* invstd, const float* coef,
-                                        int64_t rows, int C, int act, float slope, int dtype, void* stream) {
+                                        int64_t rows, int C, int act, float slope, int groups, int64_t gstride,
+                                        int64_t cstride, int dtype, void* stream) {
     int rc = check_rows_c(x, rows, C, dtype);
     if (rc) return rc;
     VG_CHECK_ARG(dy && dx && scale && shift && mean && invstd && coef, VG_EINVAL);
+    VG_CHECK_ARG(groups >= 1 && rows % groups == 0, VG_EINVAL);
     const int64_t nvec = rows * C / 4;
+    const int64_t nvg = nvec / groups;
     if (dtype == VG_F32)
         hipLaunchKernelGGL(bn_act_bwd_apply_kernel<VG_F32>, dim3(ew_blocks(nvec)), dim3(256), 0, vg_stream(stream), x,
-                           dy, dx, scale, shift, mean, invstd, coef, nvec, C / 4, C, act, slope);
+                           dy, dx, scale, shift, mean, invstd, coef, nvec, C / 4, C, act, slope, nvg, gstride, cstride);
     else
         hipLaunchKernelGGL(bn_act_bwd_apply_kernel<VG_BF16>, dim3(ew_blocks(nvec)), dim3(256), 0, vg_stream(stream), x,
-                           dy, dx, scale, shift, mean, invstd, coef, nvec, C / 4, C, act, slope);
+                           dy, dx, scale, shift, mean, invstd, coef, nvec, C / 4, C, act, slope, nvg, gstride, cstride);
     return VG_LAUNCH_RC();
 }
 

@@ -21,6 +21,7 @@
 //     wave -> LDS -> one slab row per workgroup (deterministic, no atomics).
 #include "common.hpp"
 #include <type_traits>
+#include <cstdlib>
 
 namespace {
 
@@ -334,14 +335,24 @@ inline int tiles_of(int M, int N, int bm, int bn) { return ((M + bm - 1) / bm) *
 
 // Pick the output tile: small-N layers get tall-skinny tiles (they are HBM-bound); otherwise the
 // largest tile that still fills the 256 CUs with >= ~2 workgroups each.
+inline int min_wgs() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("VG_TILE_MIN_WGS");
+        v = e ? atoi(e) : 512;
+    }
+    return v;
+}
+
 inline TileCfg pick_tile(const vg_gg_desc* d) {
     const int M = d->B * d->GH * d->GW;
     const int N = d->N;
     const int ph = d->nphase;
+    const int need = min_wgs();
     if (N <= 16) return {256, 16};
     if (N <= 32) return {128, 32};
-    if (N > 64 && tiles_of(M, N, 128, 128) * ph >= 512) return {128, 128};
-    if (tiles_of(M, N, 128, 64) * ph >= 512) return {128, 64};
+    if (N > 64 && tiles_of(M, N, 128, 128) * ph >= need) return {128, 128};
+    if (tiles_of(M, N, 128, 64) * ph >= need) return {128, 64};
     return {64, 64};
 }
 
@@ -390,6 +401,12 @@ extern "C" int vg_gather_gemm_nparts(const vg_gg_desc* d, int dtype) {
     TileCfg t = pick_tile(d);
     const int M = d->B * d->GH * d->GW;
     return d->nphase * ((M + t.bm - 1) / t.bm);
+}
+
+extern "C" int vg_gather_gemm_tile_m(const vg_gg_desc* d, int dtype) {
+    int rc = validate(d, dtype);
+    if (rc) return rc;
+    return pick_tile(d).bm;
 }
 
 extern "C" int vg_gather_gemm(const vg_gg_desc* d, int dtype, void* stream) {

@@ -160,10 +160,17 @@ template <int DT>
 __global__ __launch_bounds__(256) void dot_wgrad_kernel(const void* __restrict__ x, const float* __restrict__ dlogit,
                                                         float* __restrict__ dw, int B, int K, int C, int HW,
                                                         int accumulate) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;      // NHWC-flattened index (hw*C + c)
-    if (k >= K) return;
+    // 64 columns (NHWC-flattened k) per block x 4 batch lanes; fixed-order combine through LDS
+    __shared__ float red[4][64];
+    const int kl = threadIdx.x & 63, bl = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + kl;
     float s = 0.f;
-    for (int b = 0; b < B; ++b) s += dlogit[b] * load1<DT>(x, (int64_t)b * K + k);
+    if (k < K)
+        for (int b = bl; b < B; b += 4) s += dlogit[b] * load1<DT>(x, (int64_t)b * K + k);
+    red[bl][kl] = s;
+    __syncthreads();
+    if (bl != 0 || k >= K) return;
+    s = red[0][kl] + red[1][kl] + red[2][kl] + red[3][kl];
     const int hw = k / C, c = k - hw * C;
     float* dst = dw + (int64_t)c * HW + hw;                   // reference layout [1][C][kh][kw]
     *dst = accumulate ? (*dst + s) : s;
@@ -327,7 +334,7 @@ extern "C" int vg_dot_wgrad(const void* x, const float* dlogit, float* dw, int B
                             int dtype, void* stream) {
     CHECK_DT();
     VG_CHECK_ARG(x && dlogit && dw && B > 0 && K > 0 && C > 0 && HW > 0 && C * HW == K, VG_EINVAL);
-    DISPATCH_DT(dot_wgrad_kernel, dim3((K + 255) / 256), dim3(256), vg_stream(stream), x, dlogit, dw, B, K, C, HW,
+    DISPATCH_DT(dot_wgrad_kernel, dim3((K + 63) / 64), dim3(256), vg_stream(stream), x, dlogit, dw, B, K, C, HW,
                 accumulate);
     return VG_LAUNCH_RC();
 }

@@ -187,13 +187,41 @@ class StackEngine:
             self.pending_bn_ticks = 0
 
     # ---- forward ----------------------------------------------------------------------------------
-    def forward(self, x: torch.Tensor, B: int, train: bool, keep: bool = True):
+    def can_group(self, B: int, groups: int, probe_x: torch.Tensor) -> bool:
+        """True when `groups` independent batches of B images can run as ONE pass of groups*B images with
+        per-group BatchNorm statistics: every statistics slab (one per M tile of the conv kernel) must lie inside
+        one group.  Only plain (single-phase) convolution stacks qualify (the Discriminator)."""
+        key = ("grp", B, groups)
+        if key not in self._specs:
+            ok = True
+            packs = self._ensure_packed()
+            for i, st in enumerate(self.stages):
+                if st.kind == "head":
+                    continue
+                gg, pk = self.spec(i, B * groups, "fprop")
+                if st.bn is None:
+                    continue
+                if gg.nphase != 1 or pk.tap_in_n:
+                    ok = False
+                    break
+                xin = torch.empty(gg.B * gg.IH * gg.IW * gg.IC, dtype=ops.TORCH_DT[self.dtype], device=probe_x.device)
+                bm = ops.gather_gemm_tile_m(gg, xin, packs[i]["fprop"], self.dtype)
+                if (B * st.hout * st.hout) % bm != 0:
+                    ok = False
+                    break
+            self._specs[key] = ok
+        return self._specs[key]
+
+    def forward(self, x: torch.Tensor, B: int, train: bool, keep: bool = True, groups: int = 1):
         """x: NHWC activation of the first stage.  Returns (output, ctx).  For a 'head' last stage the
-        output is p [B] (f32); otherwise the (activated) NHWC output of the last stage."""
+        output is p [B] (f32); otherwise the (activated) NHWC output of the last stage.
+        groups > 1: x holds `groups` independent batches of B images (see can_group); BatchNorm statistics,
+        running-stat updates and coefficients are per group, in group order."""
         packs = self._ensure_packed()
         dt = self.dtype
         ctx = []
         a = x
+        Bg, B = B, B * groups
         for i, st in enumerate(self.stages):
             if st.kind == "head":
                 K = st.hin * st.hin * G.padc(st.cin, dt)
@@ -218,7 +246,8 @@ class StackEngine:
                 bn = st.bn
                 if train:
                     coeffs = ops.bn_finalize(stats, nparts, st.cout, rows, bn.weight.detach(), bn.bias.detach(),
-                                             bn.running_mean, bn.running_var, BN_MOMENTUM, BN_EPS, Y.device)
+                                             bn.running_mean, bn.running_var, BN_MOMENTUM, BN_EPS, Y.device,
+                                             groups=groups)
                 else:
                     coeffs = ops.bn_eval_coeffs(bn.weight.detach(), bn.bias.detach(), bn.running_mean,
                                                 bn.running_var, BN_EPS)
@@ -231,7 +260,7 @@ class StackEngine:
                 ctx.append({"x": a, "Y": Y, "coeffs": coeffs, "rows": rows, "OC": OC})
             a = out
         if train and any(st.bn is not None for st in self.stages):
-            self.pending_bn_ticks += 1
+            self.pending_bn_ticks += groups
         return a, (ctx, B, train)
 
     # ---- backward ---------------------------------------------------------------------------------

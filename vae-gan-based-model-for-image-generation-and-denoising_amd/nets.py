@@ -352,8 +352,8 @@ class Discriminator(_EngineNet):
         stages.append(Stage("head", chans[-1], 1, 4, 1, 0, 4, 1, conv=self.main[3 * len(chans) - 1]))
         self._engine = StackEngine(stages, self._dt, nc)
 
-    def engine_forward(self, x_nhwc, B, keep=True):
-        return self._engine.forward(x_nhwc, B, self.training, keep)
+    def engine_forward(self, x_nhwc, B, keep=True, groups=1):
+        return self._engine.forward(x_nhwc, B, self.training, keep, groups=groups)
 
     def _forward_impl(self, x, keep):
         B, C, H, W = x.shape

@@ -180,29 +180,46 @@ def wgrad(wg: WGSpec, P: torch.Tensor, Q: torch.Tensor, dW: torch.Tensor, accumu
 
 
 # ---------------------------------------------------------------------------------------------
-def bn_finalize(stats, nparts, C, count, gamma, beta, running_mean, running_var, momentum, eps, device):
-    """-> coeffs tensor [4][C]: mean, invstd, scale, shift."""
-    co = torch.empty(4, C, dtype=torch.float32, device=device)
-    L.check(L.load().vg_bn_finalize(L.ptr(stats), nparts, C, count, L.ptr(gamma), L.ptr(beta), L.ptr(running_mean),
-                                    L.ptr(running_var), momentum, eps, co[0].data_ptr(), co[1].data_ptr(),
-                                    co[2].data_ptr(), co[3].data_ptr(), L.stream_ptr()), "vg_bn_finalize")
+def gather_gemm_tile_m(g: GGSpec, X, Wp, dtype: int) -> int:
+    """M edge of the tile the launcher will pick = rows covered by one BatchNorm statistics slab."""
+    probe = _gg_desc(g, X, Wp, X, None, None, 0)
+    r = L.load().vg_gather_gemm_tile_m(byref(probe), dtype)
+    if r < 0:
+        L.check(r, "vg_gather_gemm_tile_m")
+    return r
+
+
+def bn_finalize(stats, nparts, C, count, gamma, beta, running_mean, running_var, momentum, eps, device, groups=1):
+    """-> coeffs tensor [groups][4][C]: mean, invstd, scale, shift.  With groups > 1 the slabs of group g are
+    parts [g*nparts/groups, ...) and the running statistics are updated group after group (the order in which
+    the reference runs its separate forward passes)."""
+    co = torch.empty(groups, 4, C, dtype=torch.float32, device=device)
+    npg = nparts // groups
+    for g in range(groups):
+        sp = stats.data_ptr() + g * npg * 2 * C * 4
+        L.check(L.load().vg_bn_finalize(sp, npg, C, count // groups, L.ptr(gamma), L.ptr(beta),
+                                        L.ptr(running_mean), L.ptr(running_var), momentum, eps,
+                                        co[g, 0].data_ptr(), co[g, 1].data_ptr(), co[g, 2].data_ptr(),
+                                        co[g, 3].data_ptr(), L.stream_ptr()), "vg_bn_finalize")
     return co
 
 
 def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps):
     C = running_mean.numel()
-    co = torch.empty(4, C, dtype=torch.float32, device=running_mean.device)
+    co = torch.empty(1, 4, C, dtype=torch.float32, device=running_mean.device)
     L.check(L.load().vg_bn_eval_coeffs(L.ptr(gamma), L.ptr(beta), L.ptr(running_mean), L.ptr(running_var), eps, C,
-                                       co[2].data_ptr(), co[3].data_ptr(), L.stream_ptr()), "vg_bn_eval_coeffs")
+                                       co[0, 2].data_ptr(), co[0, 3].data_ptr(), L.stream_ptr()), "vg_bn_eval_coeffs")
     return co
 
 
 def bn_act_forward(x, coeffs, rows, C, act, slope, dtype, out=None):
+    """coeffs: [groups][4][C] (or None for a pure activation)."""
     _need_cuda(x, coeffs)
     y = out if out is not None else torch.empty_like(x)
-    sc = coeffs[2].data_ptr() if coeffs is not None else 0
-    sh = coeffs[3].data_ptr() if coeffs is not None else 0
-    L.check(L.load().vg_bn_act_forward(x.data_ptr(), y.data_ptr(), sc, sh, rows, C, act, slope, dtype,
+    groups = coeffs.shape[0] if coeffs is not None else 1
+    sc = coeffs[0, 2].data_ptr() if coeffs is not None else 0
+    sh = coeffs[0, 3].data_ptr() if coeffs is not None else 0
+    L.check(L.load().vg_bn_act_forward(x.data_ptr(), y.data_ptr(), sc, sh, rows, C, act, slope, groups, 4 * C, dtype,
                                        L.stream_ptr()), "vg_bn_act_forward")
     return y
 
@@ -217,25 +234,28 @@ def channel_stats(x, rows, C, dtype):
 
 
 def bn_act_backward(x, dy, coeffs, rows, C, count, gamma, act, slope, dgamma, dbeta, accumulate, dtype):
-    """Full BN(+act) backward: returns dx (gradient w.r.t. the raw conv output)."""
+    """Full BN(+act) backward: returns dx (gradient w.r.t. the raw conv output).  coeffs: [groups][4][C]."""
     _need_cuda(x, dy, coeffs)
     lib = L.load()
+    groups = coeffs.shape[0]
     n = c_int(0)
-    cap = 1024
+    cap = 2048
     partial = WS.get("bnbwd", cap * 2 * C * 4, x.device)
-    L.check(lib.vg_bn_act_backward_reduce(x.data_ptr(), dy.data_ptr(), coeffs[2].data_ptr(), coeffs[3].data_ptr(),
-                                          coeffs[0].data_ptr(), coeffs[1].data_ptr(), rows, C, act, slope,
-                                          partial.data_ptr(), cap, byref(n), dtype, L.stream_ptr()),
-            "vg_bn_act_backward_reduce")
-    coef = torch.empty(3, C, dtype=torch.float32, device=x.device)
-    L.check(lib.vg_bn_backward_finalize(partial.data_ptr(), n.value, C, count, L.ptr(gamma), coeffs[1].data_ptr(),
-                                        L.ptr(dgamma), L.ptr(dbeta), 1 if accumulate else 0, coef.data_ptr(),
-                                        L.stream_ptr()), "vg_bn_backward_finalize")
+    L.check(lib.vg_bn_act_backward_reduce(x.data_ptr(), dy.data_ptr(), coeffs[0, 2].data_ptr(),
+                                          coeffs[0, 3].data_ptr(), coeffs[0, 0].data_ptr(), coeffs[0, 1].data_ptr(),
+                                          rows, C, act, slope, partial.data_ptr(), cap, byref(n), groups, 4 * C, dtype,
+                                          L.stream_ptr()), "vg_bn_act_backward_reduce")
+    coef = torch.empty(groups, 3, C, dtype=torch.float32, device=x.device)
+    for g in range(groups):
+        pp = partial.data_ptr() + g * n.value * 2 * C * 4
+        L.check(lib.vg_bn_backward_finalize(pp, n.value, C, count // groups, L.ptr(gamma), coeffs[g, 1].data_ptr(),
+                                            L.ptr(dgamma), L.ptr(dbeta), 1 if (accumulate or g > 0) else 0,
+                                            coef[g].data_ptr(), L.stream_ptr()), "vg_bn_backward_finalize")
     dx = torch.empty_like(x)
-    L.check(lib.vg_bn_act_backward_apply(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), coeffs[2].data_ptr(),
-                                         coeffs[3].data_ptr(), coeffs[0].data_ptr(), coeffs[1].data_ptr(),
-                                         coef.data_ptr(), rows, C, act, slope, dtype, L.stream_ptr()),
-            "vg_bn_act_backward_apply")
+    L.check(lib.vg_bn_act_backward_apply(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), coeffs[0, 2].data_ptr(),
+                                         coeffs[0, 3].data_ptr(), coeffs[0, 0].data_ptr(), coeffs[0, 1].data_ptr(),
+                                         coef.data_ptr(), rows, C, act, slope, groups, 4 * C, 3 * C, dtype,
+                                         L.stream_ptr()), "vg_bn_act_backward_apply")
     return dx
 
 
@@ -254,10 +274,10 @@ def bias_grad(dy, rows, C, NC, dbias, accumulate, dtype):
 
 
 # ---------------------------------------------------------------------------------------------
-def nchw_to_nhwc(x, CP, dtype, eps=None, sigma=0.0):
-    _need_cuda(x, eps)
+def nchw_to_nhwc(x, CP, dtype, eps=None, sigma=0.0, out=None):
+    _need_cuda(x, eps, out)
     B, C, H, W = x.shape
-    y = empty_act((B, H, W, CP), dtype, x.device)
+    y = out if out is not None else empty_act((B, H, W, CP), dtype, x.device)
     L.check(L.load().vg_nchw_to_nhwc(x.data_ptr(), L.ptr(eps), sigma, y.data_ptr(), B, C, H, W, CP, dtype,
                                      L.stream_ptr()), "vg_nchw_to_nhwc")
     return y
@@ -329,10 +349,10 @@ def dot_wgrad(x, dlogit, dw, B, K, C, HW, accumulate, dtype):
                                   1 if accumulate else 0, dtype, L.stream_ptr()), "vg_dot_wgrad")
 
 
-def bce_forward_backward(p, target, gscale, loss, accumulate, want_grad):
-    _need_cuda(p, loss)
+def bce_forward_backward(p, target, gscale, loss, accumulate, want_grad, out=None):
+    _need_cuda(p, loss, out)
     B = p.numel()
-    dp = torch.empty_like(p) if want_grad else None
+    dp = out if out is not None else (torch.empty_like(p) if want_grad else None)
     L.check(L.load().vg_bce_forward_backward(p.data_ptr(), target, B, gscale, loss.data_ptr(),
                                              1 if accumulate else 0, L.ptr(dp), L.stream_ptr()),
             "vg_bce_forward_backward")

@@ -21,7 +21,7 @@ LOSS_NAMES = ("recon_loss", "kl_loss", "g_loss_adv", "d_loss_1", "d_loss_2")
 class VAEGANTrainer:
     def __init__(self, encoder, decoder, discriminator, opt_E, opt_Dec, opt_Dis, alpha_kl: float = 0.1,
                  alpha_adv: float = 0.1, noise_sigma: float = 0.05, real_label: float = 0.9, fake_label: float = 0.1,
-                 d_iters: int = 2, elide_dead_grads: bool = False, reducer=None):
+                 d_iters: int = 2, elide_dead_grads: bool = False, reducer=None, group_d_passes: bool = True):
         self.E, self.G, self.D = encoder, decoder, discriminator
         self.opt_E, self.opt_G, self.opt_D = opt_E, opt_Dec, opt_Dis
         self.alpha_kl, self.alpha_adv, self.sigma = alpha_kl, alpha_adv, noise_sigma          # :49-50, :91-92
@@ -29,6 +29,7 @@ class VAEGANTrainer:
         # The generator-loss pass through D (vaegan_code.py:110,133) also produces D weight gradients that the
         # next opt_Dis.zero_grad() discards unread.  False = compute them anyway (what the reference executes).
         self.elide_dead_grads = elide_dead_grads
+        self.group_d_passes = group_d_passes       # run a D iteration's real+fake passes as one 2B-row launch chain
         self.reducer = reducer
         dts = {encoder._dt, decoder._dt, discriminator._dt}
         if len(dts) != 1:
@@ -67,21 +68,32 @@ class VAEGANTrainer:
         pre, ctxG = Gn.engine_forward(z, B)
         recon = ops.nhwc_to_nchw(pre, Gn.nc, dt, apply_tanh=True)
 
-        # ---- instance noise, drawn once per step (:91-92); produced directly in the layout D reads ----
+        # ---- instance noise, drawn once per step (:91-92); produced directly in the layout D reads.  Both noisy
+        # batches live in one [2B] buffer so that a Discriminator iteration can run real+fake as ONE grouped pass
+        # (per-group BatchNorm statistics, running stats updated real-then-fake as the reference's two calls do).
         CP = G.padc(D.nc, dt)
-        real_noisy = ops.nchw_to_nhwc(real, CP, dt, eps=eps_real, sigma=self.sigma)
-        recon_noisy = ops.nchw_to_nhwc(recon, CP, dt, eps=eps_recon, sigma=self.sigma)
+        both = ops.empty_act((2 * B, real.shape[2], real.shape[3], CP), dt, dev)
+        real_noisy = ops.nchw_to_nhwc(real, CP, dt, eps=eps_real, sigma=self.sigma, out=both[:B])
+        recon_noisy = ops.nchw_to_nhwc(recon, CP, dt, eps=eps_recon, sigma=self.sigma, out=both[B:])
+        grouped = self.group_d_passes and D._engine.can_group(B, 2, both)
 
         # ---- Discriminator updates (:95-105) ----
         for it in range(self.d_iters):
-            p_real, c_real = D.engine_forward(real_noisy, B)
-            p_fake, c_fake = D.engine_forward(recon_noisy, B)                                  # .detach(): no dx below
             slot = losses[3 + min(it, 1):4 + min(it, 1)]
-            dp_real = ops.bce_forward_backward(p_real, self.real_label, 1.0, slot, False, True)
-            dp_fake = ops.bce_forward_backward(p_fake, self.fake_label, 1.0, slot, True, True)
             self.opt_D.zero_grad(memset=False)
-            D._engine.backward(c_real, dp_real, False, sink)
-            D._engine.backward(c_fake, dp_fake, False, sink)
+            if grouped:
+                p_both, c_both = D.engine_forward(both, B, groups=2)                           # .detach(): no dx below
+                dp = torch.empty_like(p_both)
+                ops.bce_forward_backward(p_both[:B], self.real_label, 1.0, slot, False, True, out=dp[:B])
+                ops.bce_forward_backward(p_both[B:], self.fake_label, 1.0, slot, True, True, out=dp[B:])
+                D._engine.backward(c_both, dp, False, sink)
+            else:
+                p_real, c_real = D.engine_forward(real_noisy, B)
+                p_fake, c_fake = D.engine_forward(recon_noisy, B)
+                dp_real = ops.bce_forward_backward(p_real, self.real_label, 1.0, slot, False, True)
+                dp_fake = ops.bce_forward_backward(p_fake, self.fake_label, 1.0, slot, True, True)
+                D._engine.backward(c_real, dp_real, False, sink)
+                D._engine.backward(c_fake, dp_fake, False, sink)
             if self.reducer is not None:
                 self.reducer.reduce(self.opt_D)
             self.opt_D.step()
