@@ -74,12 +74,18 @@ typedef struct vg_gg_desc {
     int32_t ooy[VG_MAX_PHASE], oox[VG_MAX_PHASE];
     int32_t nphase;
     int32_t stats_capacity;   /* number of [2][N] slabs `stats` can hold       */
+    float*  ws;               /* optional split-K workspace (f32 partial tiles) */
+    int64_t ws_bytes;
 } vg_gg_desc;
 
 /* Number of stats slabs vg_gather_gemm will write for this descriptor (host-only query). */
 int vg_gather_gemm_nparts(const vg_gg_desc* d, int dtype);
 /* Rows (M) covered by one statistics slab = the M edge of the tile the launcher picks (host-only query). */
 int vg_gather_gemm_tile_m(const vg_gg_desc* d, int dtype);
+/* Bytes of split-K workspace this launch can use (0: the launcher will not split K).  Skinny problems -- few
+ * output tiles but a long K, e.g. the data gradient of the 1x1-input ConvTranspose2d (M=B, K=16*1024) -- are
+ * split along K over gridDim.z; the f32 partial tiles are summed in fixed order by a second kernel. */
+int64_t vg_gather_gemm_ws_bytes(const vg_gg_desc* d, int dtype);
 int vg_gather_gemm(const vg_gg_desc* d, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------

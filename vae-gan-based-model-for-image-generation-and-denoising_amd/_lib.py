@@ -33,7 +33,7 @@ class GGDesc(Structure):
                 ("N", c_int32), ("Kp", c_int32),
                 ("OH", c_int32), ("OW", c_int32), ("OC", c_int32), ("OSY", c_int32), ("OSX", c_int32),
                 ("ooy", _I4), ("oox", _I4),
-                ("nphase", c_int32), ("stats_capacity", c_int32)]
+                ("nphase", c_int32), ("stats_capacity", c_int32), ("ws", c_void_p), ("ws_bytes", c_int64)]
 
 
 class WGDesc(Structure):
@@ -63,6 +63,7 @@ SIGNATURES = {
     "vg_build_info": (c_char_p, []),
     "vg_gather_gemm_nparts": (c_int, [POINTER(GGDesc), _I]),
     "vg_gather_gemm_tile_m": (c_int, [POINTER(GGDesc), _I]),
+    "vg_gather_gemm_ws_bytes": (c_int64, [POINTER(GGDesc), _I]),
     "vg_gather_gemm": (c_int, [POINTER(GGDesc), _I, _P]),
     "vg_wgrad_ws_bytes": (c_int64, [POINTER(WGDesc), _I]),
     "vg_wgrad": (c_int, [POINTER(WGDesc), _I, _P]),

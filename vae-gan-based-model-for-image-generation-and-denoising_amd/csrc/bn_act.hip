@@ -107,7 +107,19 @@ __device__ __forceinline__ bool slab_sums(const float* __restrict__ slabs, int n
     const int c = blockIdx.x * FIN_CH + cl;
     double a = 0.0, b = 0.0;
     if (c < C) {
-        for (int p = pl; p < nparts; p += FIN_PL) {
+        // 4 slab rows (8 loads) in flight per thread: the loop is a chain of L2/HBM latencies otherwise
+        int p = pl;
+        for (; p + 3 * FIN_PL < nparts; p += 4 * FIN_PL) {
+            float x[4], y[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                x[k] = slabs[((int64_t)(p + k * FIN_PL) * 2 + 0) * C + c];
+                y[k] = slabs[((int64_t)(p + k * FIN_PL) * 2 + 1) * C + c];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { a += (double)x[k]; b += (double)y[k]; }
+        }
+        for (; p < nparts; p += FIN_PL) {
             a += (double)slabs[((int64_t)p * 2 + 0) * C + c];
             b += (double)slabs[((int64_t)p * 2 + 1) * C + c];
         }

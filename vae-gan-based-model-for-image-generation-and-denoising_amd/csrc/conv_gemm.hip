@@ -26,7 +26,7 @@
 namespace {
 
 template <int DT, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void gg_kernel(const vg_gg_desc d) {
+__global__ __launch_bounds__(256) void gg_kernel(const vg_gg_desc d, const int ksplit, const int stages_per_split) {
     typedef ElemT<DT> E;
     constexpr int ESZ = E::size;
     constexpr int TM = BM / WM / 16;
@@ -45,7 +45,8 @@ __global__ __launch_bounds__(256) void gg_kernel(const vg_gg_desc d) {
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int phase = blockIdx.z;
+    const int phase = ksplit > 1 ? 0 : blockIdx.z;          // split-K launches are single-phase: z = K slice
+    const int kz = ksplit > 1 ? blockIdx.z : 0;
     const int m0 = blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
     const int M = d.B * d.GH * d.GW;
@@ -56,7 +57,9 @@ __global__ __launch_bounds__(256) void gg_kernel(const vg_gg_desc d) {
     const int upt = (d.IC * ESZ) >> 4;             // 16-byte units per tap
     const int ntap = d.TH * d.TW;
     const int nchunks = (d.Kp * ESZ) >> 6;
-    const int nstages = (nchunks + KCH - 1) / KCH;
+    const int nstages_all = (nchunks + KCH - 1) / KCH;
+    const int s_begin = kz * stages_per_split;
+    const int nstages = min(nstages_all, s_begin + stages_per_split) - s_begin;     // stages of THIS K slice
     const uint32_t pix_bytes = (uint32_t)d.IC * ESZ;
 
     // ---- per-thread gather bases for its A rows: pixel index of tap (0,0) and its (y, x) for the bounds test ----
@@ -91,9 +94,10 @@ __global__ __launch_bounds__(256) void gg_kernel(const vg_gg_desc d) {
     }
 
     // running K position of the NEXT chunk this thread loads: tap (ta, tb), 16-byte unit cu inside the tap
-    int ld_t = q / upt, ld_cu = q - ld_t * upt;
+    const int u0 = s_begin * KCH * 4 + q;          // first 16-byte unit of this thread in this K slice
+    int ld_t = u0 / upt, ld_cu = u0 - ld_t * upt;
     int ld_ta = ld_t / d.TW, ld_tb = ld_t - ld_ta * d.TW;
-    uint32_t ld_koff = 0;                          // byte offset of the next chunk inside a packed weight row
+    uint32_t ld_koff = (uint32_t)s_begin * KCH * 64;   // byte offset of the next chunk inside a packed weight row
 
     // Two register sets: the loads of stages s+1 AND s+2 are in flight while stage s is multiplied (each stage
     // otherwise costs one full L2 round trip: the MFMAs of a stage are far shorter than the memory latency).
@@ -216,6 +220,22 @@ __global__ __launch_bounds__(256) void gg_kernel(const vg_gg_desc d) {
     }
 
     // ---------------- epilogue ----------------
+    if (ksplit > 1) {
+        // split-K: raw f32 partial tile -> workspace slab [kz][Mpad][Npad]; bias/convert happen in the reduce kernel
+        const int Npad = gridDim.y * BN;
+        float* slab = d.ws + ((int64_t)kz * gridDim.x * BM + m0) * Npad + n0;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = wm * (BM / WM) + i * 16 + fg * 4 + r;
+                    const int col = wn * (BN / WN) + j * 16 + fr;
+                    slab[(int64_t)row * Npad + col] = acc[i][j][r];
+                }
+        return;
+    }
     // (1) BatchNorm partial statistics straight from the accumulators (valid rows / real channels only);
     // (2) the C tile goes through LDS so that every lane writes one 16-byte run of channels of one output pixel
     //     (NHWC) instead of 2/4-byte scatters; output pixel offsets come from an LDS table filled once per
@@ -329,7 +349,24 @@ __global__ __launch_bounds__(256) void gg_kernel(const vg_gg_desc d) {
     }
 }
 
+template <int DT>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int ksplit, int M, int N,
+                                                            int OC, int Mpad, int Npad, const float* __restrict__ bias,
+                                                            void* __restrict__ Y) {
+    const int64_t total = (int64_t)M * OC;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / OC), n = (int)(i - (int64_t)m * OC);
+        float s = 0.f;
+        if (n < N) {
+            for (int k = 0; k < ksplit; ++k) s += ws[((int64_t)k * Mpad + m) * Npad + n];
+            if (bias) s += bias[n];
+        }
+        store1<DT>(Y, i, s);
+    }
+}
+
 struct TileCfg { int bm, bn; };
+struct SplitK { int ksplit, sps; int64_t ws_bytes; };
 
 inline int tiles_of(int M, int N, int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); }
 
@@ -376,21 +413,52 @@ inline int validate(const vg_gg_desc* d, int dtype) {
     return 0;
 }
 
-template <int DT, int BM, int BN, int WM, int WN>
-int launch(const vg_gg_desc* d, hipStream_t s) {
+// Split K only for skinny problems: one phase, flat output, no BN statistics, <= 32 output tiles, >= 16 stages.
+inline SplitK plan_splitk(const vg_gg_desc* d, int dtype, TileCfg t) {
+    SplitK r{1, 0, 0};
     const int M = d->B * d->GH * d->GW;
-    dim3 grid((M + BM - 1) / BM, (d->N + BN - 1) / BN, d->nphase);
-    hipLaunchKernelGGL((gg_kernel<DT, BM, BN, WM, WN>), grid, dim3(256), 0, s, *d);
+    const bool flat = d->nphase == 1 && d->OSY == 1 && d->OSX == 1 && d->GH == d->OH && d->GW == d->OW;
+    if (!flat || d->stats != nullptr) return r;
+    const int esz = dtype == VG_F32 ? 4 : 2;
+    const int kch = dtype == VG_BF16 ? 2 : 1;
+    const int nstages = ((d->Kp * esz) / 64 + kch - 1) / kch;
+    const int gx = (M + t.bm - 1) / t.bm, gy = (d->N + t.bn - 1) / t.bn;
+    const int tiles = gx * gy;
+    if (tiles > 32 || nstages < 16) return r;
+    int ks = 256 / tiles;
+    if (ks > nstages / 4) ks = nstages / 4;
+    if (ks < 2) return r;
+    r.sps = (nstages + ks - 1) / ks;
+    r.ksplit = (nstages + r.sps - 1) / r.sps;
+    r.ws_bytes = (int64_t)r.ksplit * gx * t.bm * (int64_t)(gy * t.bn) * 4;
+    return r;
+}
+
+template <int DT, int BM, int BN, int WM, int WN>
+int launch(const vg_gg_desc* d, hipStream_t s, SplitK sk) {
+    const int M = d->B * d->GH * d->GW;
+    const bool split = sk.ksplit > 1 && d->ws != nullptr && d->ws_bytes >= sk.ws_bytes;
+    dim3 grid((M + BM - 1) / BM, (d->N + BN - 1) / BN, split ? sk.ksplit : d->nphase);
+    const int nstages_all = 1 << 30;
+    hipLaunchKernelGGL((gg_kernel<DT, BM, BN, WM, WN>), grid, dim3(256), 0, s, *d, split ? sk.ksplit : 1,
+                       split ? sk.sps : nstages_all);
+    int rc = VG_LAUNCH_RC();
+    if (rc || !split) return rc;
+    const int64_t total = (int64_t)M * d->OC;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel<DT>, dim3(blocks), dim3(256), 0, s, d->ws, sk.ksplit, M, d->N, d->OC,
+                       (int)grid.x * BM, (int)grid.y * BN, d->bias, d->Y);
     return VG_LAUNCH_RC();
 }
 
 template <int DT>
-int dispatch(const vg_gg_desc* d, TileCfg t, hipStream_t s) {
-    if (t.bm == 256 && t.bn == 16) return launch<DT, 256, 16, 4, 1>(d, s);
-    if (t.bm == 128 && t.bn == 32) return launch<DT, 128, 32, 4, 1>(d, s);
-    if (t.bm == 128 && t.bn == 128) return launch<DT, 128, 128, 2, 2>(d, s);
-    if (t.bm == 128 && t.bn == 64) return launch<DT, 128, 64, 2, 2>(d, s);
-    return launch<DT, 64, 64, 2, 2>(d, s);
+int dispatch(const vg_gg_desc* d, TileCfg t, hipStream_t s, SplitK sk) {
+    if (t.bm == 256 && t.bn == 16) return launch<DT, 256, 16, 4, 1>(d, s, sk);
+    if (t.bm == 128 && t.bn == 32) return launch<DT, 128, 32, 4, 1>(d, s, sk);
+    if (t.bm == 128 && t.bn == 128) return launch<DT, 128, 128, 2, 2>(d, s, sk);
+    if (t.bm == 128 && t.bn == 64) return launch<DT, 128, 64, 2, 2>(d, s, sk);
+    return launch<DT, 64, 64, 2, 2>(d, s, sk);
 }
 
 }  // namespace
@@ -409,14 +477,21 @@ extern "C" int vg_gather_gemm_tile_m(const vg_gg_desc* d, int dtype) {
     return pick_tile(d).bm;
 }
 
+extern "C" int64_t vg_gather_gemm_ws_bytes(const vg_gg_desc* d, int dtype) {
+    int rc = validate(d, dtype);
+    if (rc) return rc;
+    return plan_splitk(d, dtype, pick_tile(d)).ws_bytes;
+}
+
 extern "C" int vg_gather_gemm(const vg_gg_desc* d, int dtype, void* stream) {
     int rc = validate(d, dtype);
     if (rc) return rc;
     TileCfg t = pick_tile(d);
+    const SplitK sk = plan_splitk(d, dtype, t);
     if (d->stats) {
         const int M = d->B * d->GH * d->GW;
         VG_CHECK_ARG(d->stats_capacity >= d->nphase * ((M + t.bm - 1) / t.bm), VG_EINVAL);
     }
-    if (dtype == VG_F32) return dispatch<VG_F32>(d, t, vg_stream(stream));
-    return dispatch<VG_BF16>(d, t, vg_stream(stream));
+    if (dtype == VG_F32) return dispatch<VG_F32>(d, t, vg_stream(stream), sk);
+    return dispatch<VG_BF16>(d, t, vg_stream(stream), sk);
 }

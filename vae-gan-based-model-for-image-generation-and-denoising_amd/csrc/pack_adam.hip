@@ -65,7 +65,30 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const vg_pack_desc* __r
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         const bool pow2 = (ntap & (ntap - 1)) == 0;
         const int sh = 31 - __builtin_clz(ntap);
-        if (d.s_c <= d.s_n) {
+        const bool vec4 = (ntap == PK_TT) && ((d.s_n | d.s_c | tap0) % 4 == 0) &&
+                          ((reinterpret_cast<uintptr_t>(d.src) & 15u) == 0);
+        if (vec4) {
+            // 16-tap tiles: 1024 float4 per block, 4 per thread, all in flight at once
+            float4 v[4];
+            int nn_[4], cc_[4], t4_[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int idx = k * 256 + threadIdx.x;            // 0..1023
+                int nn, cc, t4;
+                if (d.s_c <= d.s_n) { t4 = (idx & 3) * 4; cc = (idx >> 2) & (PK_CT - 1); nn = idx >> 8; }   // [n][c][tap]
+                else { t4 = (idx & 3) * 4; nn = (idx >> 2) & (PK_NT - 1); cc = idx >> 4; }                  // [c][n][tap]
+                nn_[k] = nn; cc_[k] = cc; t4_[k] = t4;
+                const int n = n0 + nn, c = c0 + cc;
+                v[k] = float4{0.f, 0.f, 0.f, 0.f};
+                if (n < rowsN && c < d.C)
+                    v[k] = *reinterpret_cast<const float4*>(d.src + (int64_t)n * d.s_n + (int64_t)c * d.s_c + tap0 + t4);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float* t = &tile[nn_[k]][cc_[k]][t4_[k]];
+                t[0] = v[k].x; t[1] = v[k].y; t[2] = v[k].z; t[3] = v[k].w;
+            }
+        } else if (d.s_c <= d.s_n) {
             // [n][c][tap] source: for a fixed n the (c, tap) block is one contiguous run -> wave = n row
             const int n = n0 + wave;
             for (int e = lane; e < PK_CT * ntap; e += 64) {

@@ -148,6 +148,10 @@ def gather_gemm(g: GGSpec, X: torch.Tensor, Wp: torch.Tensor, dtype: int, bias: 
             L.check(nparts, "vg_gather_gemm_nparts")
         stats = WS.get("stats", nparts * 2 * g.N * 4, X.device)
     d = _gg_desc(g, X, Wp, Y, bias, stats, nparts)
+    wsb = lib.vg_gather_gemm_ws_bytes(byref(d), dtype)
+    if wsb > 0:
+        ws = WS.get("splitk", wsb, X.device)
+        d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * 4
     tok = TIMER.begin("gather_gemm", *(alg or (g.flops(), 0))) if TIMER is not None else None
     L.check(lib.vg_gather_gemm(byref(d), dtype, L.stream_ptr()), "vg_gather_gemm")
     if tok is not None:
