@@ -27,6 +27,16 @@ import torch.distributed as dist  # noqa: E402
 # ALGORITHMIC conv/convT/linear FLOP per image per step (fwd + wgrad + dgrad, D x5)
 ALG_GFLOP_PER_IMAGE = {64: 6.45, 128: 8.77, 256: 12.561}
 PEAK = {"fp32": 157.3, "bf16": 2500.0}          # dense MFMA TFLOP/s, MI355X_MICROARCH.md
+# HBM-side bytes per gather-GEMM launch from the rocprofv3 PMC passes committed under profiles/ (separate
+# --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command; FETCH_SIZE doubled per the gfx950 correction of
+# MI355X_MICROARCH.md section HBM, counters in KiB): measured offline, NOT re-measured by this run.
+def pmc_traffic(dtype):
+    """bytes per gather-GEMM launch from the committed PMC summary (profiles/r01_<dtype>_pmc_traffic.json)."""
+    f = os.path.join(ROOT, "profiles", f"r01_{dtype}_pmc_traffic.json")
+    try:
+        return round(json.load(open(f))["families"]["gather_gemm"]["hbm_bytes_per_launch"])
+    except Exception:
+        return None
 HBM_PEAK_GBS = 8000.0
 
 
@@ -70,7 +80,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=int, default=64)
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch")
-    ap.add_argument("--dtype", default=os.environ.get("VAEGAN_BENCH_DTYPE", "fp32"), choices=["fp32", "bf16"])
+    ap.add_argument("--dtype", default=os.environ.get("VAEGAN_BENCH_DTYPE", "bf16"), choices=["fp32", "bf16"],
+                    help="bf16 = BASELINE configs[1] (bf16 storage, f32 accumulate, fp32 master weights); fp32 = parity path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("VAEGAN_BENCH_GRAPH", "1")),
                     help="1: replay the iteration from one captured hipGraph (single GPU only)")

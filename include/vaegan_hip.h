@@ -42,6 +42,11 @@ extern "C" {
 #define VG_ACT_LRELU   2   /* nn.LeakyReLU(slope)    main_vae.py:25, gan_code.py:62-82 */
 
 int vg_abi_version(void);
+/* Live kernel timing for the roofline report: while enabled, gather-GEMM (family 0) and wgrad (family 1)
+ * launches carry a HIP start/stop event pair on their stream (hipExtLaunchKernelGGL); collect() synchronises,
+ * sums the kernel times in ms, returns the launch count and resets the family.  Do not enable during capture. */
+int vg_timing_enable(int on);
+int vg_timing_collect(int family, double* total_ms /* host */, int* launches /* host */);
 /* Which tile configuration the launcher would pick (for tests / bench reporting). */
 const char* vg_build_info(void);
 

@@ -249,6 +249,21 @@ def test_step_is_bitwise_deterministic():
         assert torch.equal(a, b)
 
 
+def test_bf16_engine_tracks_fp32_oracle():
+    """bf16 storage / f32 accumulate / fp32 master weights (the throughput path, BASELINE configs[1]) against the
+    fp32 CPU oracle: first-iteration losses within 3e-2 (bf16 has 8 significant bits; stated bf16 tolerance)."""
+    S, B = 64, 16
+    e, g, d, tr = build(S, dtype="bf16")
+    o = R.RefVAEGAN(img_size=S, seed=42)
+    real, ez, er, ec = make_inputs(B, S, 7000 + S)
+    ref = o.train_step(real, ez, er, ec, 60)
+    got = tr.loss_dict(tr.train_step(real.to(DEV), 60, ez.to(DEV), er.to(DEV), ec.to(DEV)), 60)
+    for n in V.LOSS_NAMES:
+        assert rel(got[n], ref[n]) <= 3e-2, f"bf16 {n}: hip {got[n]} oracle {ref[n]}"
+    for p in list(e.parameters()) + list(g.parameters()) + list(d.parameters()):
+        assert p.dtype == torch.float32 and bool(torch.isfinite(p).all())
+
+
 def test_grouped_discriminator_pass_equals_separate_passes():
     """One grouped 2B-row pass per D iteration (per-group BatchNorm statistics) vs the reference's two calls."""
     outs = []

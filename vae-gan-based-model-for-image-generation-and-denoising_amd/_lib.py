@@ -61,6 +61,8 @@ _P, _F, _I, _L, _D = c_void_p, c_float, c_int, c_int64, c_double
 SIGNATURES = {
     "vg_abi_version": (c_int, []),
     "vg_build_info": (c_char_p, []),
+    "vg_timing_enable": (c_int, [_I]),
+    "vg_timing_collect": (c_int, [_I, POINTER(c_double), POINTER(c_int)]),
     "vg_gather_gemm_nparts": (c_int, [POINTER(GGDesc), _I]),
     "vg_gather_gemm_tile_m": (c_int, [POINTER(GGDesc), _I]),
     "vg_gather_gemm_ws_bytes": (c_int64, [POINTER(GGDesc), _I]),

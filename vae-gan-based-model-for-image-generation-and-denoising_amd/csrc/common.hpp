@@ -88,3 +88,35 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+
+// ---- optional live kernel timing (bench.py roofline leg) ------------------------------------------------------
+// When enabled, the GEMM-class launches go through hipExtLaunchKernelGGL with a start/stop event pair, which
+// brackets the kernel itself on its stream (no launch latency inside the bracket, unlike events recorded around
+// the launch call).  Off by default and never on while a stream is being captured into a graph.
+#include <hip/hip_ext.h>
+#include <mutex>
+#include <vector>
+struct VgTiming {
+    bool on = false;
+    std::mutex mu;
+    std::vector<hipEvent_t> pool;                                 // free events
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> rec[2];         // family 0: gather-GEMM, 1: wgrad
+};
+VgTiming& vg_timing();
+
+template <typename K, typename... Args>
+inline void vg_launch_timed(int family, K kernel, dim3 grid, dim3 block, size_t shm, hipStream_t s, Args... args) {
+    VgTiming& t = vg_timing();
+    if (!t.on) {
+        hipLaunchKernelGGL(kernel, grid, block, shm, s, args...);
+        return;
+    }
+    hipEvent_t e0, e1;
+    {
+        std::lock_guard<std::mutex> g(t.mu);
+        auto get = [&]() { hipEvent_t e; if (t.pool.empty()) { (void)hipEventCreate(&e); } else { e = t.pool.back(); t.pool.pop_back(); } return e; };
+        e0 = get(); e1 = get();
+        t.rec[family].push_back({e0, e1});
+    }
+    hipExtLaunchKernelGGL(kernel, grid, block, shm, s, e0, e1, 0, args...);
+}

@@ -440,8 +440,8 @@ int launch(const vg_gg_desc* d, hipStream_t s, SplitK sk) {
     const bool split = sk.ksplit > 1 && d->ws != nullptr && d->ws_bytes >= sk.ws_bytes;
     dim3 grid((M + BM - 1) / BM, (d->N + BN - 1) / BN, split ? sk.ksplit : d->nphase);
     const int nstages_all = 1 << 30;
-    hipLaunchKernelGGL((gg_kernel<DT, BM, BN, WM, WN>), grid, dim3(256), 0, s, *d, split ? sk.ksplit : 1,
-                       split ? sk.sps : nstages_all);
+    vg_launch_timed(0, gg_kernel<DT, BM, BN, WM, WN>, grid, dim3(256), 0, s, *d, split ? sk.ksplit : 1,
+                    split ? sk.sps : nstages_all);
     int rc = VG_LAUNCH_RC();
     if (rc || !split) return rc;
     const int64_t total = (int64_t)M * d->OC;

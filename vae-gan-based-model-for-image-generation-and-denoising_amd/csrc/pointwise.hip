@@ -366,5 +366,36 @@ extern "C" int vg_axpy(const float* a, const float* b, float alpha, float* out, 
     return VG_LAUNCH_RC();
 }
 
+VgTiming& vg_timing() {
+    static VgTiming t;
+    return t;
+}
+
+extern "C" int vg_timing_enable(int on) {
+    VgTiming& t = vg_timing();
+    std::lock_guard<std::mutex> g(t.mu);
+    t.on = on != 0;
+    return 0;
+}
+
+// Synchronises the recorded events of `family`, returns the summed kernel time and the launch count, recycles them.
+extern "C" int vg_timing_collect(int family, double* total_ms, int* launches) {
+    VG_CHECK_ARG(family >= 0 && family < 2 && total_ms && launches, VG_EINVAL);
+    VgTiming& t = vg_timing();
+    std::lock_guard<std::mutex> g(t.mu);
+    double sum = 0.0;
+    for (auto& pr : t.rec[family]) {
+        (void)hipEventSynchronize(pr.second);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) sum += ms;
+        t.pool.push_back(pr.first);
+        t.pool.push_back(pr.second);
+    }
+    *total_ms = sum;
+    *launches = (int)t.rec[family].size();
+    t.rec[family].clear();
+    return 0;
+}
+
 extern "C" int vg_abi_version(void) { return 1; }
 extern "C" const char* vg_build_info(void) { return "vaegan_hip gfx950: gather-GEMM f32(16x16x4)/bf16(16x16x32) MFMA"; }

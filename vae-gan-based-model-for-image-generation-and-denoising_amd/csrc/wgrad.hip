@@ -416,9 +416,9 @@ extern "C" int vg_wgrad(const vg_wg_desc* d, int dtype, void* stream) {
     hipStream_t s = vg_stream(stream);
     dim3 grid(p.tiles_kq, p.tiles_np, p.nsplit);
     if (dtype == VG_F32)
-        hipLaunchKernelGGL(wgrad_kernel<VG_F32>, grid, dim3(256), 0, s, *d, p.rows_per_split, p.KQ, p.NPpad);
+        vg_launch_timed(1, wgrad_kernel<VG_F32>, grid, dim3(256), 0, s, *d, p.rows_per_split, p.KQ, p.NPpad);
     else
-        hipLaunchKernelGGL(wgrad_bf16_kernel, grid, dim3(256), 0, s, *d, p.rows_per_split, p.KQ, p.NPpad);
+        vg_launch_timed(1, wgrad_bf16_kernel, grid, dim3(256), 0, s, *d, p.rows_per_split, p.KQ, p.NPpad);
     rc = VG_LAUNCH_RC();
     if (rc) return rc;
     const bool vec = (d->NQ % 4 == 0) && (d->QC % 4 == 0);

@@ -44,31 +44,33 @@ WS = _Workspace()
 
 
 class KernelTimer:
-    """Optional live timing of the GEMM-class launches with HIP events recorded on the launch stream
-    (bench.py's roofline leg).  Off by default: no events are created unless a timer is installed."""
+    """Live timing of the GEMM-class launches (bench.py's roofline leg): the library brackets each kernel with a
+    HIP start/stop event pair on its launch stream (vg_timing_*); this object only adds up the algorithmic
+    FLOP / bytes of the same launches.  Off by default."""
+    FAMILIES = {"gather_gemm": 0, "wgrad": 1}
 
     def __init__(self):
-        self.rec = []          # (family, flops, bytes, ev0, ev1)
+        self.acc = {k: dict(flops=0, bytes=0) for k in self.FAMILIES}
+        L.load().vg_timing_enable(1)
 
     def begin(self, family, flops, nbytes):
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
-        return (family, flops, nbytes, e0, e1)
+        self.acc[family]["flops"] += flops
+        self.acc[family]["bytes"] += nbytes
+        return None
 
     def end(self, tok):
-        tok[4].record()
-        self.rec.append(tok)
+        pass
 
     def summary(self):
-        """family -> dict(launches, ms, flops, bytes); call after a device synchronise."""
+        """family -> dict(launches, ms, flops, bytes); synchronises the recorded events and stops timing."""
+        import ctypes
         out = {}
-        for fam, fl, nb, e0, e1 in self.rec:
-            d = out.setdefault(fam, dict(launches=0, ms=0.0, flops=0, bytes=0))
-            d["launches"] += 1
-            d["ms"] += e0.elapsed_time(e1)
-            d["flops"] += fl
-            d["bytes"] += nb
+        lib = L.load()
+        for fam, idx in self.FAMILIES.items():
+            ms, n = ctypes.c_double(0.0), ctypes.c_int(0)
+            L.check(lib.vg_timing_collect(idx, ctypes.byref(ms), ctypes.byref(n)), "vg_timing_collect")
+            out[fam] = dict(launches=n.value, ms=ms.value, **self.acc[fam])
+        lib.vg_timing_enable(0)
         return out
 
 
