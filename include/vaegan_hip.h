@@ -81,6 +81,8 @@ typedef struct vg_gg_desc {
     int32_t stats_capacity;   /* number of [2][N] slabs `stats` can hold       */
     float*  ws;               /* optional split-K workspace (f32 partial tiles) */
     int64_t ws_bytes;
+    const void* zeros;        /* >= 64 zero bytes, 16-byte aligned: source of out-of-image taps on the LDS-DMA path
+                                 (NULL selects the register-staged path)       */
 } vg_gg_desc;
 
 /* Number of stats slabs vg_gather_gemm will write for this descriptor (host-only query). */

@@ -33,7 +33,7 @@ class GGDesc(Structure):
                 ("N", c_int32), ("Kp", c_int32),
                 ("OH", c_int32), ("OW", c_int32), ("OC", c_int32), ("OSY", c_int32), ("OSX", c_int32),
                 ("ooy", _I4), ("oox", _I4),
-                ("nphase", c_int32), ("stats_capacity", c_int32), ("ws", c_void_p), ("ws_bytes", c_int64)]
+                ("nphase", c_int32), ("stats_capacity", c_int32), ("ws", c_void_p), ("ws_bytes", c_int64), ("zeros", c_void_p)]
 
 
 class WGDesc(Structure):
@@ -96,7 +96,7 @@ SIGNATURES = {
     "vg_adam_step": (c_int, [_P, _P, _P, _P, _L, _D, _D, _D, _D, _F, _P, _P]),
 }
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libvaegan_hip.so")
+LIB_PATH = os.environ.get("VG_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libvaegan_hip.so")
 _lib = None
 
 

@@ -25,21 +25,58 @@
 
 namespace {
 
-template <int DT, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void gg_kernel(const vg_gg_desc d, const int ksplit, const int stages_per_split) {
+#define VG_WAITCNT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+
+// wait until at most n vector-memory operations of this wave are outstanding (n = DMA instructions that may stay
+// in flight); the immediate must be a literal, so the few values that occur are enumerated (wave-uniform switch)
+__device__ __forceinline__ void wait_vmcnt_le(int n) {
+    switch (n) {
+        case 2: VG_WAITCNT_VM(2); break;
+        case 3: VG_WAITCNT_VM(3); break;
+        case 4: VG_WAITCNT_VM(4); break;
+        case 6: VG_WAITCNT_VM(6); break;
+        case 8: VG_WAITCNT_VM(8); break;
+        case 9: VG_WAITCNT_VM(9); break;
+        case 12: VG_WAITCNT_VM(12); break;
+        case 16: VG_WAITCNT_VM(16); break;
+        case 18: VG_WAITCNT_VM(18); break;
+        case 24: VG_WAITCNT_VM(24); break;
+        default: VG_WAITCNT_VM(0); break;
+    }
+}
+
+// LDS-DMA ring shape (measured, S=64 B=128 layer sweep): the 128x128 tile wants ONE 64-byte chunk per stage
+// (3 x 16 KB ring = 48 KB -> 3 workgroups per CU: G2 445 -> 690, G3 424 -> 622 TFLOP/s), the smaller tiles two.
+#ifndef VG_DMA_NBUF
+#define VG_DMA_NBUF 3
+#endif
+
+template <int DT, int BM, int BN, int WM, int WN, bool SPLITK, bool DMA>
+__global__ __launch_bounds__(256) void gg_kernel(const vg_gg_desc d, const int ksplit_arg, const int stages_per_split) {
+    const int ksplit = SPLITK ? ksplit_arg : 1;        // compile-time 1 on the common path (keeps its registers lean)
     typedef ElemT<DT> E;
     constexpr int ESZ = E::size;
     constexpr int TM = BM / WM / 16;
     constexpr int TN = BN / WN / 16;
     constexpr int AP = BM / 64;                    // A row passes per chunk
     constexpr int BP = (BN + 63) / 64;             // B row passes per chunk
-    constexpr int KCH = (DT == VG_BF16) ? 2 : 1;   // 64-byte K chunks per barrier (bf16 MFMAs are 16x shorter)
+    // 64-byte K chunks per barrier (bf16 MFMAs are 16x shorter than f32 ones)
+#ifdef VG_DMA_KCH
+    constexpr int KCH = DMA ? VG_DMA_KCH : ((DT == VG_BF16) ? 2 : 1);
+#else
+    constexpr int KCH = DMA ? ((BM * BN >= 128 * 128) ? 1 : 2) : ((DT == VG_BF16) ? 2 : 1);
+#endif
     constexpr int CHB = (BM + BN) * 64;            // bytes of one chunk image
     constexpr int STAGE = CHB * KCH;               // bytes per LDS buffer
+    constexpr int NBUF = DMA ? VG_DMA_NBUF : 2;    // DMA path: LDS ring, NBUF-1 stages in flight
     static_assert(WM * WN == 4, "4 waves");
     static_assert(BM % 64 == 0, "BM multiple of 64");
+    static_assert(!DMA || BN % 64 == 0, "DMA path needs whole 16-row wave slices of the B tile");
 
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+    // ONE shared object (a second one next to an LDS-DMA target can make hipcc drain vmcnt before every ds_read):
+    // [NBUF stage buffers][output-pixel table of the epilogue]
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NBUF * STAGE + BM * 4];
+    int* const opix_tab = reinterpret_cast<int*>(smem + NBUF * STAGE);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -53,7 +90,9 @@ __global__ __launch_bounds__(256) void gg_kernel(const vg_gg_desc d, const int k
     const int GHW = d.GH * d.GW;
 
     const int lrow = tid >> 2;                     // 0..63
-    const int q = tid & 3;                         // 16-byte unit within the chunk
+    // 16-byte unit within the chunk.  Register path: the LDS slot is swizzled when written.  DMA path: a lane's
+    // LDS slot is fixed (base + lane*16), so the swizzle moves to the SOURCE unit it fetches (same involution).
+    const int q = DMA ? ((tid & 3) ^ ((-(lrow >> 2)) & 3)) : (tid & 3);
     const int upt = (d.IC * ESZ) >> 4;             // 16-byte units per tap
     const int ntap = d.TH * d.TW;
     const int nchunks = (d.Kp * ESZ) >> 6;
@@ -164,6 +203,9 @@ __global__ __launch_bounds__(256) void gg_kernel(const vg_gg_desc d, const int k
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
     auto compute = [&](int buf) {
+#ifdef VG_ABLATE_COMPUTE
+        return;
+#endif
 #pragma unroll
         for (int c = 0; c < KCH; ++c) {
             const unsigned char* sa = smem + buf * STAGE + c * CHB;
@@ -179,6 +221,13 @@ __global__ __launch_bounds__(256) void gg_kernel(const vg_gg_desc d, const int k
                 const int r = wn * (BN / WN) + j * 16 + fr;
                 fb[j] = *reinterpret_cast<const u32x4*>(sb + r * 64 + ((fg ^ ((-(r >> 2)) & 3)) << 4));
             }
+#ifdef VG_ABLATE_MFMA
+#pragma unroll
+            for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(fa[i]));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(fb[j]));
+            continue;
+#endif
             if constexpr (DT == VG_F32) {
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk)
@@ -199,28 +248,91 @@ __global__ __launch_bounds__(256) void gg_kernel(const vg_gg_desc d, const int k
         }
     };
 
+    if constexpr (DMA) {
+        // ---- LDS-DMA main loop: global_load_lds_dwordx4 straight into a 3-deep LDS ring -------------------------
+        // No staging registers and no ds_write (the 128x128 bf16 tile was LDS-bound on its ds_write_b128 traffic).
+        // Out-of-image taps / rows beyond M or N / the K tail fetch from a 64-byte zero page instead.
+        // Ordering (cdna_hip_programming.md "Pipelining across barriers"): counted s_waitcnt vmcnt(L) leaves the
+        // next stage in flight, then a raw s_barrier; the buffer refilled at iteration s was last read at s-1.
+        constexpr int LDMA = KCH * (AP + BP);                         // DMA instructions per wave per stage
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+        // zero page addressed relative to the same base as the data, so a lane's source is ONE selected offset
+        // (a pointer select makes hipcc emit two exec-masked DMA instructions per load)
+        const int64_t zoffA = reinterpret_cast<const unsigned char*>(d.zeros) - Xb;
+        const int64_t zoffB = reinterpret_cast<const unsigned char*>(d.zeros) - Wb;
+        auto issue_stage = [&](int buf) {
+#pragma unroll
+            for (int c = 0; c < KCH; ++c) {
+                const bool uok = ld_t < ntap && ld_koff < wrow_bytes;
+                const int dy = d.DY * ld_ta, dx = d.DX * ld_tb;
+                const int dpix = dy * d.IW + dx;
+                unsigned char* sa = smem + buf * STAGE + c * CHB;
+                unsigned char* sb = sa + BM * 64;
+#pragma unroll
+                for (int i = 0; i < AP; ++i) {
+                    const bool ok = uok && (unsigned)(a_iy[i] + dy) < (unsigned)d.IH &&
+                                    (unsigned)(a_ix[i] + dx) < (unsigned)d.IW;
+                    const int64_t off = ok ? (int64_t)((uint32_t)(a_pix[i] + dpix) * pix_bytes + (uint32_t)ld_cu * 16u) : zoffA;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Xb + off),
+                                                     (__attribute__((address_space(3))) void*)(sa + (64 * i + 16 * wave_u) * 64),
+                                                     16, 0, 0);
+                }
+#pragma unroll
+                for (int j = 0; j < BP; ++j) {
+                    const int64_t off = (b_ok[j] && ld_koff < wrow_bytes) ? (int64_t)(b_ptr[j] - Wb) + ld_koff : zoffB;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wb + off),
+                                                     (__attribute__((address_space(3))) void*)(sb + (64 * j + 16 * wave_u) * 64),
+                                                     16, 0, 0);
+                }
+                ld_koff += 64;
+                ld_cu += 4;
+                while (ld_cu >= upt) {
+                    ld_cu -= upt;
+                    ++ld_t;
+                    if (++ld_tb == d.TW) { ld_tb = 0; ++ld_ta; }
+                }
+            }
+        };
+#pragma unroll
+        for (int p = 0; p < NBUF - 1; ++p)
+            if (p < nstages) issue_stage(p);
+        int rb = 0, wb = NBUF - 1;                                     // ring: read s % NBUF, write (s + NBUF-1) % NBUF
+        for (int ks = 0; ks < nstages; ++ks) {
+            // stages ks+1 .. ks+NBUF-2 may stay in flight; stage ks must have landed
+            const int ahead = min(NBUF - 2, nstages - 1 - ks);
+            wait_vmcnt_le(ahead * LDMA);
+            __builtin_amdgcn_s_barrier();
+#ifndef VG_ABLATE_LOAD
+            if (ks + NBUF - 1 < nstages) issue_stage(wb);
+#endif
+            compute(rb);
+            rb = rb == NBUF - 1 ? 0 : rb + 1;
+            wb = wb == NBUF - 1 ? 0 : wb + 1;
+        }
+    } else {
     // prologue: stage 0 -> LDS buffer 0; stages 1 and 2 in flight in register sets 1 and 0
-    load_stage(S0{});
-    store_stage(0, S0{});
-    if (nstages > 1) load_stage(S1{});
-    if (nstages > 2) load_stage(S0{});
-    __syncthreads();
-    // steady state, unrolled by two so that register-set indices are compile-time constants:
-    //   compute(s) ; store(s+1) from its set ; refill that set with stage s+3 ; barrier
-    for (int ks = 0; ks < nstages; ks += 2) {
-        compute(0);
-        if (ks + 1 < nstages) store_stage(1, S1{});
-        if (ks + 3 < nstages) load_stage(S1{});
+        load_stage(S0{});
+        store_stage(0, S0{});
+        if (nstages > 1) load_stage(S1{});
+        if (nstages > 2) load_stage(S0{});
         __syncthreads();
-        if (ks + 1 >= nstages) break;
-        compute(1);
-        if (ks + 2 < nstages) store_stage(0, S0{});
-        if (ks + 4 < nstages) load_stage(S0{});
-        __syncthreads();
+        // steady state, unrolled by two so that register-set indices are compile-time constants:
+        //   compute(s) ; store(s+1) from its set ; refill that set with stage s+3 ; barrier
+        for (int ks = 0; ks < nstages; ks += 2) {
+            compute(0);
+            if (ks + 1 < nstages) store_stage(1, S1{});
+            if (ks + 3 < nstages) load_stage(S1{});
+            __syncthreads();
+            if (ks + 1 >= nstages) break;
+            compute(1);
+            if (ks + 2 < nstages) store_stage(0, S0{});
+            if (ks + 4 < nstages) load_stage(S0{});
+            __syncthreads();
+        }
     }
 
     // ---------------- epilogue ----------------
-    if (ksplit > 1) {
+    if constexpr (SPLITK) {
         // split-K: raw f32 partial tile -> workspace slab [kz][Mpad][Npad]; bias/convert happen in the reduce kernel
         const int Npad = gridDim.y * BN;
         float* slab = d.ws + ((int64_t)kz * gridDim.x * BM + m0) * Npad + n0;
@@ -240,7 +352,6 @@ __global__ __launch_bounds__(256) void gg_kernel(const vg_gg_desc d, const int k
     // (2) the C tile goes through LDS so that every lane writes one 16-byte run of channels of one output pixel
     //     (NHWC) instead of 2/4-byte scatters; output pixel offsets come from an LDS table filled once per
     //     workgroup (no per-element integer division for the sub-pixel scatter).
-    __shared__ int opix_tab[BM];
     const bool flat = (d.nphase == 1 && d.OSY == 1 && d.OSX == 1 && d.GH == d.OH && d.GW == d.OW);
     for (int r = tid; r < BM; r += 256) {
         const int m = m0 + r;
@@ -312,10 +423,10 @@ __global__ __launch_bounds__(256) void gg_kernel(const vg_gg_desc d, const int k
     }
 
     // C tile staging: pitch padded by 16 B; the tile is written in NPASS row blocks when it exceeds the LDS buffers
-    constexpr int NPASS = (BM * (BN * ESZ + 16) <= 2 * STAGE) ? 1 : WM;
+    constexpr int NPASS = (BM * (BN * ESZ + 16) <= NBUF * STAGE) ? 1 : WM;
     constexpr int PROWS = BM / NPASS;
-    constexpr int CPITCH = BN * ESZ + ((PROWS * (BN * ESZ + 16) <= 2 * STAGE) ? 16 : 0);
-    static_assert(PROWS * CPITCH <= 2 * STAGE, "C tile pass does not fit in LDS");
+    constexpr int CPITCH = BN * ESZ + ((PROWS * (BN * ESZ + 16) <= NBUF * STAGE) ? 16 : 0);
+    static_assert(PROWS * CPITCH <= NBUF * STAGE, "C tile pass does not fit in LDS");
     constexpr int SEGS = BN * ESZ / 16;                // 16-byte segments per tile row
     unsigned char* Yb = reinterpret_cast<unsigned char*>(d.Y);
     const int oc_bytes = d.OC * ESZ;
@@ -372,6 +483,15 @@ inline int tiles_of(int M, int N, int bm, int bn) { return ((M + bm - 1) / bm) *
 
 // Pick the output tile: small-N layers get tall-skinny tiles (they are HBM-bound); otherwise the
 // largest tile that still fills the 256 CUs with >= ~2 workgroups each.
+inline bool use_dma() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("VG_GG_DMA");
+        v = e ? atoi(e) : 1;
+    }
+    return v != 0;
+}
+
 inline int min_wgs() {
     static int v = -1;
     if (v < 0) {
@@ -440,8 +560,16 @@ int launch(const vg_gg_desc* d, hipStream_t s, SplitK sk) {
     const bool split = sk.ksplit > 1 && d->ws != nullptr && d->ws_bytes >= sk.ws_bytes;
     dim3 grid((M + BM - 1) / BM, (d->N + BN - 1) / BN, split ? sk.ksplit : d->nphase);
     const int nstages_all = 1 << 30;
-    vg_launch_timed(0, gg_kernel<DT, BM, BN, WM, WN>, grid, dim3(256), 0, s, *d, split ? sk.ksplit : 1,
-                    split ? sk.sps : nstages_all);
+    constexpr bool CAN_DMA = (DT == VG_BF16) && (BN % 64 == 0);
+    const bool dma = CAN_DMA && use_dma() && d->zeros != nullptr;
+    if (split) {
+        vg_launch_timed(0, gg_kernel<DT, BM, BN, WM, WN, true, false>, grid, dim3(256), 0, s, *d, sk.ksplit, sk.sps);
+    } else if constexpr (CAN_DMA) {
+        if (dma) vg_launch_timed(0, gg_kernel<DT, BM, BN, WM, WN, false, true>, grid, dim3(256), 0, s, *d, 1, nstages_all);
+        else vg_launch_timed(0, gg_kernel<DT, BM, BN, WM, WN, false, false>, grid, dim3(256), 0, s, *d, 1, nstages_all);
+    } else {
+        vg_launch_timed(0, gg_kernel<DT, BM, BN, WM, WN, false, false>, grid, dim3(256), 0, s, *d, 1, nstages_all);
+    }
     int rc = VG_LAUNCH_RC();
     if (rc || !split) return rc;
     const int64_t total = (int64_t)M * d->OC;

@@ -119,8 +119,19 @@ def pack_weights_multi(table: torch.Tensor, n: int, max_elems: int, dtype: int) 
             "vg_pack_weights_multi")
 
 
+_ZEROS = {}
+
+
+def zero_page(device) -> torch.Tensor:
+    z = _ZEROS.get(str(device))
+    if z is None:
+        z = torch.zeros(64, dtype=torch.float32, device=device)      # 256 zero bytes
+        _ZEROS[str(device)] = z
+    return z
+
+
 def _gg_desc(g: GGSpec, X, Wp, Y, bias, stats, cap) -> L.GGDesc:
-    return L.GGDesc(X=X.data_ptr(), W=Wp.data_ptr(), Y=Y.data_ptr(),
+    return L.GGDesc(zeros=zero_page(X.device).data_ptr(), X=X.data_ptr(), W=Wp.data_ptr(), Y=Y.data_ptr(),
                     bias=0 if bias is None else bias.data_ptr(), stats=0 if stats is None else stats.data_ptr(),
                     B=g.B, GH=g.GH, GW=g.GW, IH=g.IH, IW=g.IW, IC=g.IC, SY=g.SY, SX=g.SX, DY=g.DY, DX=g.DX,
                     TH=g.TH, TW=g.TW, y0=L.i4(g.y0), x0=L.i4(g.x0), N=g.N, Kp=g.Kp, OH=g.OH, OW=g.OW, OC=g.OC,
