@@ -115,6 +115,7 @@ typedef struct vg_wg_desc {
     int32_t SY, SX, DY, DX, TH, TW, y0, x0;
     int32_t s_np, s_cq, s_t;          /* element strides into dW               */
     int32_t accumulate;
+    const void* zeros;                /* >= 64 zero bytes (16-byte aligned) for the LDS-DMA path; NULL = register path */
 } vg_wg_desc;
 
 int64_t vg_wgrad_ws_bytes(const vg_wg_desc* d, int dtype);

@@ -43,7 +43,7 @@ class WGDesc(Structure):
                 ("QH", c_int32), ("QW", c_int32), ("QC", c_int32), ("NQ", c_int32),
                 ("SY", c_int32), ("SX", c_int32), ("DY", c_int32), ("DX", c_int32), ("TH", c_int32), ("TW", c_int32),
                 ("y0", c_int32), ("x0", c_int32),
-                ("s_np", c_int32), ("s_cq", c_int32), ("s_t", c_int32), ("accumulate", c_int32)]
+                ("s_np", c_int32), ("s_cq", c_int32), ("s_t", c_int32), ("accumulate", c_int32), ("zeros", c_void_p)]
 
 
 class PackDesc(Structure):

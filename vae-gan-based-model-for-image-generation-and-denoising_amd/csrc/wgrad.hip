@@ -14,6 +14,7 @@
 // element [4*step + k][16*tile + i], 16 consecutive floats per k row; rows are padded to 80
 // floats so the two k rows of a 32-lane ds_read_b32 group hit disjoint bank halves.
 #include "common.hpp"
+#include <cstdlib>
 
 namespace {
 
@@ -296,6 +297,138 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const vg_wg_desc d, int
             }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// LDS-DMA variant of the bf16 kernel (opt-in, VG_WG_DMA=1): same 128x128 tile, MFMA and transposed fragment reads, but the
+// operands go global -> LDS with global_load_lds_dwordx4 into a 3-deep ring of 32-row stages (3 x 16 KB = 48 KB,
+// three workgroups per CU), no staging registers, no ds_write.  One wave instruction writes 4 rows x 256 B; a
+// lane's row is 16j + 4*wave + (lane>>4), so (row & 7) -- the swizzle key -- does not depend on j and every lane
+// fetches ONE fixed swizzled source unit (one fixed filter tap / channel offset) for the whole kernel.  Rows past
+// the split range, channels past the tensor and out-of-image taps fetch from a zero page.
+constexpr int WD_SM = 32, WD_NBUF = 3, WD_STAGE = 2 * WD_SM * WB_PITCH;     // 16 KB per stage (P | Q)
+
+#define WG_WAITCNT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+
+__global__ __launch_bounds__(256) void wgrad_bf16_dma_kernel(const vg_wg_desc d, int rows_per_split, int KQ, int NPpad) {
+    // one shared object: [ring of stages][row tables: 4 x 32 x {image base, iy0, ix0}]
+    __shared__ __attribute__((aligned(16))) unsigned char smem[WD_NBUF * WD_STAGE + 4 * WD_SM * 3 * 4];
+    int* const rowtab = reinterpret_cast<int*>(smem + WD_NBUF * WD_STAGE);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int wnp = wave >> 1, wkq = wave & 1;
+    const int kq0 = blockIdx.x * WB_T;
+    const int np0 = blockIdx.y * WB_T;
+    const int M = d.B * d.GH * d.GW;
+    const int GHW = d.GH * d.GW;
+    const int m_begin = blockIdx.z * rows_per_split;
+    const int m_end = min(M, m_begin + rows_per_split);
+
+    const int rsub = lane >> 4;                              // row within the 4-row group of one DMA instruction
+    const int upos = lane & 15;                              // 16-byte position within the 256-byte LDS row
+    const int key = (4 * wave + rsub) & 7;                   // row & 7 for every row this lane ever loads
+    const int unit = (((upos >> 1) ^ key) << 1) | (upos & 1);   // swizzled SOURCE unit (8 bf16 columns)
+    const int kq_e = kq0 + unit * 8;
+    const bool q_ok = kq_e < KQ;
+    const int t = q_ok ? kq_e / d.QC : 0;
+    const int cq = kq_e - t * d.QC;
+    const int ta = t / d.TW, tb = t - ta * d.TW;
+    const int qdy = d.DY * ta, qdx = d.DX * tb;
+    const bool p_ok = np0 + unit * 8 < d.PC;
+    const unsigned char* Pb = reinterpret_cast<const unsigned char*>(d.P);
+    const unsigned char* Qb = reinterpret_cast<const unsigned char*>(d.Q);
+    const int64_t zoffP = reinterpret_cast<const unsigned char*>(d.zeros) - Pb;
+    const int64_t zoffQ = reinterpret_cast<const unsigned char*>(d.zeros) - Qb;
+
+    auto fill_table = [&](int slot, int ms) {
+        if (tid < WD_SM) {
+            const int m = ms + tid;
+            int base = 0, iy0 = -(1 << 28), ix0 = 0;
+            if (m < m_end) {
+                const int b = m / GHW;
+                const int r = m - b * GHW;
+                const int gy = r / d.GW;
+                const int gx = r - gy * d.GW;
+                base = b * d.QH * d.QW;
+                iy0 = gy * d.SY + d.y0;
+                ix0 = gx * d.SX + d.x0;
+            }
+            int* e = rowtab + (slot * WD_SM + tid) * 3;
+            e[0] = base; e[1] = iy0; e[2] = ix0;
+        }
+    };
+    auto issue_stage = [&](int buf, int slot, int ms) {
+        unsigned char* sp = smem + buf * WD_STAGE;
+        unsigned char* sq = sp + WD_SM * WB_PITCH;
+#pragma unroll
+        for (int j = 0; j < WD_SM / 16; ++j) {
+            const int r = 16 * j + 4 * wave + rsub;
+            const int m = ms + r;
+            const int64_t offp = (p_ok && m < m_end) ? ((int64_t)m * d.PC + np0 + unit * 8) * 2 : zoffP;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Pb + offp),
+                                             (__attribute__((address_space(3))) void*)(sp + (16 * j + 4 * wave_u) * WB_PITCH),
+                                             16, 0, 0);
+            const int* e = rowtab + (slot * WD_SM + r) * 3;
+            const int iy = e[1] + qdy, ix = e[2] + qdx;
+            const bool ok = q_ok && (unsigned)iy < (unsigned)d.QH && (unsigned)ix < (unsigned)d.QW;
+            const int64_t offq = ok ? ((int64_t)(e[0] + iy * d.QW + ix) * d.QC + cq) * 2 : zoffQ;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Qb + offq),
+                                             (__attribute__((address_space(3))) void*)(sq + (16 * j + 4 * wave_u) * WB_PITCH),
+                                             16, 0, 0);
+        }
+    };
+    constexpr int LDMA = 2 * (WD_SM / 16);                   // DMA instructions per wave per stage (= 4)
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nstage = (m_end - m_begin + WD_SM - 1) / WD_SM;
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+        if (p < nstage) fill_table(p, m_begin + p * WD_SM);
+    __syncthreads();
+    if (nstage > 0) issue_stage(0, 0, m_begin);
+    if (nstage > 1) issue_stage(1, 1, m_begin + WD_SM);
+    int rb = 0, wb = 2;
+    for (int s = 0; s < nstage; ++s) {
+        if (s + 1 < nstage) WG_WAITCNT_VM(4);                // LDMA: stage s+1 may stay in flight
+        else WG_WAITCNT_VM(0);
+        __builtin_amdgcn_s_barrier();
+        if (s + 2 < nstage) issue_stage(wb, (s + 2) & 3, m_begin + (s + 2) * WD_SM);
+        if (s + 3 < nstage) fill_table((s + 3) & 3, m_begin + (s + 3) * WD_SM);
+        const unsigned char* sp = smem + rb * WD_STAGE;
+        const unsigned char* sq = sp + WD_SM * WB_PITCH;
+        bf16x8 a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = tr_frag(sp, 0, wnp * 64 + i * 16, lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = tr_frag(sq, 0, wkq * 64 + j * 16, lane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        rb = rb == 2 ? 0 : rb + 1;
+        wb = wb == 2 ? 0 : wb + 1;
+    }
+    static_assert(LDMA == 4, "vmcnt literal above assumes 4 DMA instructions per stage");
+    float* slab = d.ws + (int64_t)blockIdx.z * NPpad * (int64_t)(gridDim.x * WB_T);
+    const int ldk = gridDim.x * WB_T;
+    const int fi = lane & 15, fk = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int np = np0 + wnp * 64 + i * 16 + fk * 4 + r;
+                const int kq = kq0 + wkq * 64 + j * 16 + fi;
+                slab[(int64_t)np * ldk + kq] = acc[i][j][r];
+            }
+}
+
 // Sum the split slabs in fixed order and write the reference parameter layout.  One thread owns VC consecutive
 // gathered channels (cq) of one np row and walks its T filter taps: per split lane the slab reads are 16-byte
 // vectors that form whole 128-byte lines across the EL threads of a block, and the T taps of a weight row are
@@ -365,6 +498,17 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const vg_wg_desc d, i
 
 struct Plan { int tiles_kq, tiles_np, nsplit, rows_per_split, KQ, NPpad, tile; int64_t ws_bytes; };
 
+inline bool wg_use_dma(const vg_wg_desc* d) {
+    static int v = -1;
+    if (v < 0) {
+        // opt-in: measured 3 % SLOWER than the register-staged kernel on the S=64 B=128 step (3.81 vs 3.72 ms):
+        // 32-row stages give only 16 MFMAs per barrier, and slab write + reduce are ~25 % of wgrad time either way
+        const char* e = getenv("VG_WG_DMA");
+        v = e ? atoi(e) : 0;
+    }
+    return v != 0 && d->zeros != nullptr;
+}
+
 inline int make_plan(const vg_wg_desc* d, int dtype, Plan* p) {
     VG_CHECK_ARG(d != nullptr, VG_EINVAL);
     VG_CHECK_ARG(dtype == VG_F32 || dtype == VG_BF16, VG_ENOSUP);
@@ -377,7 +521,7 @@ inline int make_plan(const vg_wg_desc* d, int dtype, Plan* p) {
     VG_CHECK_ARG(M < (1ll << 31), VG_EINVAL);
     p->KQ = d->TH * d->TW * d->QC;
     const int tile = dtype == VG_F32 ? WG_BNP : WB_T;          // output tile edge
-    const int srows = dtype == VG_F32 ? WG_BMK : WB_SM;        // pixel rows per stage
+    const int srows = dtype == VG_F32 ? WG_BMK : (wg_use_dma(d) ? WD_SM : WB_SM);     // pixel rows per stage
     p->tile = tile;
     p->tiles_kq = (p->KQ + tile - 1) / tile;
     p->tiles_np = (d->PC + tile - 1) / tile;
@@ -386,7 +530,7 @@ inline int make_plan(const vg_wg_desc* d, int dtype, Plan* p) {
     int64_t stages = (M + srows - 1) / srows;
     int nsplit = (int)((512 + tiles - 1) / tiles);            // ~2 workgroups per CU
     // at least 8 (f32) / 4 (bf16) stages of work per workgroup, at most 1024 splits
-    const int min_stages = dtype == VG_F32 ? 8 : 4;
+    const int min_stages = dtype == VG_F32 ? 8 : (wg_use_dma(d) ? 8 : 4);
     if (nsplit > stages / min_stages) nsplit = (int)(stages / min_stages);
     if (nsplit < 1) nsplit = 1;
     if (nsplit > 1024) nsplit = 1024;
@@ -417,6 +561,8 @@ extern "C" int vg_wgrad(const vg_wg_desc* d, int dtype, void* stream) {
     dim3 grid(p.tiles_kq, p.tiles_np, p.nsplit);
     if (dtype == VG_F32)
         vg_launch_timed(1, wgrad_kernel<VG_F32>, grid, dim3(256), 0, s, *d, p.rows_per_split, p.KQ, p.NPpad);
+    else if (wg_use_dma(d))
+        vg_launch_timed(1, wgrad_bf16_dma_kernel, grid, dim3(256), 0, s, *d, p.rows_per_split, p.KQ, p.NPpad);
     else
         vg_launch_timed(1, wgrad_bf16_kernel, grid, dim3(256), 0, s, *d, p.rows_per_split, p.KQ, p.NPpad);
     rc = VG_LAUNCH_RC();

@@ -183,7 +183,7 @@ def wgrad(wg: WGSpec, P: torch.Tensor, Q: torch.Tensor, dW: torch.Tensor, accumu
     d = L.WGDesc(P=P.data_ptr(), Q=Q.data_ptr(), dW=dW.data_ptr(), ws=0, ws_bytes=0, B=wg.B, GH=wg.GH, GW=wg.GW,
                  PC=wg.PC, NP=wg.NP, QH=wg.QH, QW=wg.QW, QC=wg.QC, NQ=wg.NQ, SY=wg.SY, SX=wg.SX, DY=wg.DY,
                  DX=wg.DX, TH=wg.TH, TW=wg.TW, y0=wg.y0, x0=wg.x0, s_np=wg.s_np, s_cq=wg.s_cq, s_t=wg.s_t,
-                 accumulate=1 if accumulate else 0)
+                 accumulate=1 if accumulate else 0, zeros=zero_page(P.device).data_ptr())
     nbytes = lib.vg_wgrad_ws_bytes(byref(d), dtype)
     if nbytes < 0:
         L.check(int(nbytes), "vg_wgrad_ws_bytes")
