@@ -198,6 +198,10 @@ int vg_bias_grad(const void* dy, int64_t rows, int C, int NC, float* dbias, int 
  * instance noise out = x + sigma*eps (vaegan_code.py:91-92), eps NCHW f32 or NULL. */
 int vg_nchw_to_nhwc(const float* x, const float* eps, float sigma, void* y,
                     int B, int C, int H, int W, int CP, int dtype, void* stream);
+/* Denoise-evaluation input (vaegan_code.py:153-154): noisy = clamp(x + sigma*eps, lo, hi), written both as the
+ * NHWC engine tensor and (optionally, y_nchw != NULL) as NCHW f32 for the caller. */
+int vg_noisy_clamp_to_nhwc(const float* x, const float* eps, float sigma, float lo, float hi, void* y,
+                           float* y_nchw, int B, int C, int H, int W, int CP, int dtype, void* stream);
 /* NHWC dtype -> NCHW f32, optional tanh (gan_code.py:50). */
 int vg_nhwc_to_nchw(const void* x, float* y, int B, int C, int H, int W, int CP,
                     int apply_tanh, int dtype, void* stream);
@@ -232,6 +236,10 @@ int vg_bce_forward_backward(const float* p, float target, int B, float gscale,
 /* nn.MSELoss(mean) (vaegan_code.py:47) on NCHW f32 tensors; d_a = gscale*2*(a-b)/n (NULL ok). */
 int vg_mse_forward_backward(const float* a, const float* b, int64_t n, float gscale,
                             float* loss, float* d_a, float* ws, int ws_capacity, void* stream);
+/* Mean SSIM of two NCHW f32 image batches in [-1,1] (rescaled to [0,1] as vaegan_code.py:170-174 does):
+ * gaussian 11x11, sigma 1.5, k1 .01, k2 .03, data_range 1, 5-pixel border cropped.  out[0] = mean. */
+int vg_ssim(const float* a, const float* b, int B, int C, int H, int W, float* out, float* ws, int ws_capacity,
+            void* stream);
 /* out = a + alpha*b (f32, n elements); used for gradient joins on NCHW images. */
 int vg_axpy(const float* a, const float* b, float alpha, float* out, int64_t n, void* stream);
 /* PSNR/SSIM support for the denoise path lives in vg_image_metrics. */

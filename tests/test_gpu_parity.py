@@ -391,3 +391,26 @@ def test_adam_state_dict_roundtrip_and_checkpoint_keys():
     # decoder checkpoint (vaegan_code.py:193) loads into a fresh module with identical keys
     g2 = V.Generator(nz=100, img_size=64)
     g2.load_state_dict(g.state_dict())
+
+
+@pytest.mark.parametrize("S,sigma", [(64, 0.2), (64, 0.05), (128, 0.2)])
+def test_denoise_eval_path_vs_oracle(S, sigma):
+    """BASELINE config 4 / vaegan_code.py:147-171: eval-mode E -> reparam -> G on clamp(img + sigma*eps, -1, 1),
+    MSE + KL(sum), PSNR and SSIM (oracle restatement of the torchmetrics SSIM recipe; parity unpinned)."""
+    B = 8
+    e, g, d, tr = build(S)
+    o = R.RefVAEGAN(img_size=S, seed=42)
+    real, ez, er, ec = make_inputs(B, S, 7000 + S)
+    o.train_step(real, ez, er, ec, 60)                        # one training step so BN running stats are non-trivial
+    tr.train_step(real.to(DEV), 60, ez.to(DEV), er.to(DEV), ec.to(DEV))
+    sync_from_oracle(o, e, g, d, tr)                          # identical weights / buffers for the eval comparison
+    e.eval(), g.eval()
+    img, ez2, noise, _ = make_inputs(B, S, 31337 + S)
+    noisy_ref, recon_ref, rl_ref, kl_ref = o.denoise(img, sigma * noise, ez2)
+    out = V.denoise_eval(e, g, img.to(DEV), sigma=sigma, eps=noise.to(DEV), eps_z=ez2.to(DEV))
+    torch.testing.assert_close(out["noisy"].cpu(), noisy_ref, rtol=0, atol=1e-6)
+    torch.testing.assert_close(out["recon"].cpu(), recon_ref, rtol=1e-3, atol=2e-5)
+    assert rel(out["recon_loss"], rl_ref) < 1e-4 and rel(out["kl_loss"], kl_ref) < 1e-4
+    a01, b01 = (recon_ref + 1) / 2, (img + 1) / 2
+    assert abs(out["psnr"] - R.psnr(a01, b01)) < 1e-3
+    assert abs(out["ssim"] - R.ssim(a01, b01)) < 1e-4

@@ -82,6 +82,7 @@ SIGNATURES = {
     "vg_act_backward": (c_int, [_P, _P, _P, _L, _I, _F, _I, _P]),
     "vg_bias_grad": (c_int, [_P, _L, _I, _I, _P, _I, _P, _I, _I, _P]),
     "vg_nchw_to_nhwc": (c_int, [_P, _P, _F, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "vg_noisy_clamp_to_nhwc": (c_int, [_P, _P, _F, _F, _F, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "vg_nhwc_to_nchw": (c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "vg_nchw_grad_to_nhwc": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "vg_reparam_forward": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
@@ -92,6 +93,7 @@ SIGNATURES = {
     "vg_dot_wgrad": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "vg_bce_forward_backward": (c_int, [_P, _F, _I, _F, _P, _I, _P, _P]),
     "vg_mse_forward_backward": (c_int, [_P, _P, _L, _F, _P, _P, _P, _I, _P]),
+    "vg_ssim": (c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _I, _P]),
     "vg_axpy": (c_int, [_P, _P, _F, _P, _L, _P]),
     "vg_adam_step": (c_int, [_P, _P, _P, _P, _L, _D, _D, _D, _D, _F, _P, _P]),
 }

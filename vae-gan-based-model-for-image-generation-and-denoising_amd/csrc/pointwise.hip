@@ -9,7 +9,7 @@ namespace {
 template <int DT>
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, const float* __restrict__ eps,
                                                            float sigma, void* __restrict__ y, int64_t npix, int C,
-                                                           int HW, int CP) {
+                                                           int HW, int CP, float lo, float hi, float* __restrict__ y_nchw) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t b = i / HW;
         const int64_t hw = i - b * HW;
@@ -19,6 +19,8 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
                 const int64_t src = (b * C + c) * HW + hw;
                 v = x[src];
                 if (eps) v = v + sigma * eps[src];
+                v = fminf(fmaxf(v, lo), hi);
+                if (y_nchw) y_nchw[src] = v;
             }
             store1<DT>(y, i * CP + c, v);
         }
@@ -240,6 +242,49 @@ __global__ __launch_bounds__(256) void axpy_kernel(const float* __restrict__ a, 
         out[i] = a[i] + alpha * b[i];
 }
 
+// ---- SSIM (denoise evaluation, vaegan_code.py:143,174): gaussian 11x11 (sigma 1.5), reflect padding, per-channel
+// maps, border of 5 cropped before averaging (the torchmetrics recipe restated in oracle/vaegan_ref.py:ssim;
+// parity unpinned -- torchmetrics is not installed).  Inputs NCHW f32 in [-1,1], mapped to [0,1] on the fly.
+__global__ __launch_bounds__(256) void ssim_kernel(const float* __restrict__ a, const float* __restrict__ b, int BC, int H,
+                                                   int W, float* __restrict__ partial) {
+    __shared__ float g[11];
+    __shared__ double red[4];
+    if (threadIdx.x < 11) {
+        float s = 0.f;
+        for (int k = 0; k < 11; ++k) s += expf(-((k - 5) * (k - 5)) / (2.f * 1.5f * 1.5f));
+        g[threadIdx.x] = expf(-((int(threadIdx.x) - 5) * (int(threadIdx.x) - 5)) / (2.f * 1.5f * 1.5f)) / s;
+    }
+    __syncthreads();
+    const int IH = H - 10, IW = W - 10;                     // interior kept after the crop
+    const int64_t total = (int64_t)BC * IH * IW;
+    const float c1 = 0.01f * 0.01f, c2 = 0.03f * 0.03f;
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % IW) + 5;
+        const int y = (int)((i / IW) % IH) + 5;
+        const int64_t pl = i / ((int64_t)IW * IH);
+        const float* pa = a + pl * H * W;
+        const float* pb = b + pl * H * W;
+        float ma = 0.f, mb = 0.f, saa = 0.f, sbb = 0.f, sab = 0.f;
+        for (int dy = -5; dy <= 5; ++dy) {
+            const int yy = y + dy;                              // interior pixels never need the reflect
+            const float gy = g[dy + 5];
+            for (int dx = -5; dx <= 5; ++dx) {
+                const float w = gy * g[dx + 5];
+                const float va = (pa[yy * W + x + dx] + 1.f) * 0.5f;
+                const float vb = (pb[yy * W + x + dx] + 1.f) * 0.5f;
+                ma += w * va; mb += w * vb; saa += w * va * va; sbb += w * vb * vb; sab += w * va * vb;
+            }
+        }
+        const float vaa = saa - ma * ma, vbb = sbb - mb * mb, vab = sab - ma * mb;
+        acc += (double)(((2.f * ma * mb + c1) * (2.f * vab + c2)) / ((ma * ma + mb * mb + c1) * (vaa + vbb + c2)));
+    }
+    acc = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (float)(red[0] + red[1] + red[2] + red[3]);
+}
+
 inline int blocks_for(int64_t n, int cap = 4096) {
     int64_t b = (n + 255) / 256;
     if (b > cap) b = cap;
@@ -263,7 +308,17 @@ extern "C" int vg_nchw_to_nhwc(const float* x, const float* eps, float sigma, vo
     VG_CHECK_ARG(x && y && B > 0 && C > 0 && H > 0 && W > 0 && CP >= C, VG_EINVAL);
     const int64_t npix = (int64_t)B * H * W;
     DISPATCH_DT(nchw_to_nhwc_kernel, dim3(blocks_for(npix)), dim3(256), vg_stream(stream), x, eps, sigma, y, npix, C,
-                H * W, CP);
+                H * W, CP, -3.0e38f, 3.0e38f, (float*)nullptr);
+    return VG_LAUNCH_RC();
+}
+
+extern "C" int vg_noisy_clamp_to_nhwc(const float* x, const float* eps, float sigma, float lo, float hi, void* y,
+                                      float* y_nchw, int B, int C, int H, int W, int CP, int dtype, void* stream) {
+    CHECK_DT();
+    VG_CHECK_ARG(x && eps && y && B > 0 && C > 0 && H > 0 && W > 0 && CP >= C && lo <= hi, VG_EINVAL);
+    const int64_t npix = (int64_t)B * H * W;
+    DISPATCH_DT(nchw_to_nhwc_kernel, dim3(blocks_for(npix)), dim3(256), vg_stream(stream), x, eps, sigma, y, npix, C,
+                H * W, CP, lo, hi, y_nchw);
     return VG_LAUNCH_RC();
 }
 
@@ -357,6 +412,19 @@ extern "C" int vg_mse_forward_backward(const float* a, const float* b, int64_t n
     int rc = VG_LAUNCH_RC();
     if (rc) return rc;
     hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(64), 0, vg_stream(stream), ws, blocks, (double)n, loss);
+    return VG_LAUNCH_RC();
+}
+
+extern "C" int vg_ssim(const float* a, const float* b, int B, int C, int H, int W, float* out, float* ws,
+                       int ws_capacity, void* stream) {
+    VG_CHECK_ARG(a && b && out && ws && B > 0 && C > 0 && H > 10 && W > 10 && ws_capacity >= 1, VG_EINVAL);
+    const int64_t total = (int64_t)B * C * (H - 10) * (W - 10);
+    int blocks = blocks_for(total, 1024);
+    if (blocks > ws_capacity) blocks = ws_capacity;
+    hipLaunchKernelGGL(ssim_kernel, dim3(blocks), dim3(256), 0, vg_stream(stream), a, b, B * C, H, W, ws);
+    int rc = VG_LAUNCH_RC();
+    if (rc) return rc;
+    hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(64), 0, vg_stream(stream), ws, blocks, (double)total, out);
     return VG_LAUNCH_RC();
 }
 

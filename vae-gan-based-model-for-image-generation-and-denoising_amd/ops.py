@@ -300,6 +300,28 @@ def nchw_to_nhwc(x, CP, dtype, eps=None, sigma=0.0, out=None):
     return y
 
 
+def noisy_clamp_to_nhwc(x, eps, sigma, CP, dtype, lo=-1.0, hi=1.0):
+    """-> (noisy NHWC engine tensor, noisy NCHW f32)."""
+    _need_cuda(x, eps)
+    B, C, H, W = x.shape
+    y = empty_act((B, H, W, CP), dtype, x.device)
+    yn = torch.empty_like(x)
+    L.check(L.load().vg_noisy_clamp_to_nhwc(x.data_ptr(), eps.data_ptr(), sigma, lo, hi, y.data_ptr(), yn.data_ptr(),
+                                            B, C, H, W, CP, dtype, L.stream_ptr()), "vg_noisy_clamp_to_nhwc")
+    return y, yn
+
+
+def ssim(a, b):
+    """Mean SSIM of two NCHW f32 batches in [-1,1] -> device scalar tensor [1]."""
+    _need_cuda(a, b)
+    B, C, H, W = a.shape
+    out = torch.empty(1, dtype=torch.float32, device=a.device)
+    ws = WS.get("mse", 1024 * 4, a.device)
+    L.check(L.load().vg_ssim(a.data_ptr(), b.data_ptr(), B, C, H, W, out.data_ptr(), ws.data_ptr(), 1024,
+                             L.stream_ptr()), "vg_ssim")
+    return out
+
+
 def nhwc_to_nchw(x, C, dtype, apply_tanh=False):
     _need_cuda(x)
     B, H, W, CP = x.shape
