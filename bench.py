@@ -37,6 +37,8 @@ def pmc_traffic(dtype):
         return round(json.load(open(f))["families"]["gather_gemm"]["hbm_bytes_per_launch"])
     except Exception:
         return None
+
+
 HBM_PEAK_GBS = 8000.0
 
 
@@ -179,7 +181,9 @@ def main():
     ach = gg["flops"] / (gg["ms"] * 1e-3) / 1e12
     roofline = {"bound": "mfma", "kernel": "gg_kernel (gather-GEMM: conv/convT/linear fprop + dgrad)",
                 "achieved": round(ach, 2), "peak": PEAK[args.dtype], "unit": "TFLOP/s",
-                "frac": round(ach / PEAK[args.dtype], 4), "traffic": None,
+                "frac": round(ach / PEAK[args.dtype], 4),
+                # HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/), not re-measured here
+                "traffic": pmc_traffic(args.dtype) if (S, B) == (64, 128) else None,
                 "launches_per_step": gg["launches"] // args.steps,
                 "avg_launch_us": round(gg["ms"] * 1e3 / max(gg["launches"], 1), 2),
                 "alg_gflop_per_launch": round(gg["flops"] / max(gg["launches"], 1) / 1e9, 3),

@@ -30,7 +30,7 @@ def fam_of(name):
 def main():
     tag, trace_dir = sys.argv[1], sys.argv[2]
     here = os.path.dirname(os.path.abspath(__file__))
-    stats = sorted(glob.glob(os.path.join(trace_dir, "*", "*kernel_stats.csv")))[-1]
+    stats = max(glob.glob(os.path.join(trace_dir, "*", "*kernel_stats.csv")), key=os.path.getmtime)
     shutil.copy(stats, os.path.join(here, f"{tag}_kernel_stats.csv"))
     rows = list(csv.DictReader(open(stats)))
     total = sum(int(r["TotalDurationNs"]) for r in rows)
@@ -42,7 +42,7 @@ def main():
         out["families"][fam] = {"launches": calls, "avg_us": ns / max(calls, 1) / 1e3, "share": ns / total}
     if len(sys.argv) >= 5:
         for key, d in (("fetch_kib", sys.argv[3]), ("write_kib", sys.argv[4])):
-            f = sorted(glob.glob(os.path.join(d, "*", "*counter_collection.csv")))[-1]
+            f = max(glob.glob(os.path.join(d, "*", "*counter_collection.csv")), key=os.path.getmtime)
             acc = collections.defaultdict(lambda: [0, 0.0])
             for r in csv.DictReader(open(f)):
                 fam = fam_of(r["Kernel_Name"])
