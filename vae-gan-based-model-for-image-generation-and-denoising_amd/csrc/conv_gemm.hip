@@ -501,7 +501,9 @@ inline int min_wgs() {
     return v;
 }
 
-inline TileCfg pick_tile(const vg_gg_desc* d) {
+// (a 256x128 tile -- wave tile 128x64, 152 VGPRs, one wave per SIMD -- was measured and loses on every layer)
+inline TileCfg pick_tile(const vg_gg_desc* d, bool bf16 = false) {
+    (void)bf16;
     const int M = d->B * d->GH * d->GW;
     const int N = d->N;
     const int ph = d->nphase;
@@ -594,7 +596,7 @@ int dispatch(const vg_gg_desc* d, TileCfg t, hipStream_t s, SplitK sk) {
 extern "C" int vg_gather_gemm_nparts(const vg_gg_desc* d, int dtype) {
     int rc = validate(d, dtype);
     if (rc) return rc;
-    TileCfg t = pick_tile(d);
+    TileCfg t = pick_tile(d, dtype == VG_BF16);
     const int M = d->B * d->GH * d->GW;
     return d->nphase * ((M + t.bm - 1) / t.bm);
 }
@@ -602,19 +604,19 @@ extern "C" int vg_gather_gemm_nparts(const vg_gg_desc* d, int dtype) {
 extern "C" int vg_gather_gemm_tile_m(const vg_gg_desc* d, int dtype) {
     int rc = validate(d, dtype);
     if (rc) return rc;
-    return pick_tile(d).bm;
+    return pick_tile(d, dtype == VG_BF16).bm;
 }
 
 extern "C" int64_t vg_gather_gemm_ws_bytes(const vg_gg_desc* d, int dtype) {
     int rc = validate(d, dtype);
     if (rc) return rc;
-    return plan_splitk(d, dtype, pick_tile(d)).ws_bytes;
+    return plan_splitk(d, dtype, pick_tile(d, dtype == VG_BF16)).ws_bytes;
 }
 
 extern "C" int vg_gather_gemm(const vg_gg_desc* d, int dtype, void* stream) {
     int rc = validate(d, dtype);
     if (rc) return rc;
-    TileCfg t = pick_tile(d);
+    TileCfg t = pick_tile(d, dtype == VG_BF16);
     const SplitK sk = plan_splitk(d, dtype, t);
     if (d->stats) {
         const int M = d->B * d->GH * d->GW;
