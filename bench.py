@@ -86,7 +86,7 @@ def main():
                     help="bf16 = BASELINE configs[1] (bf16 storage, f32 accumulate, fp32 master weights); fp32 = parity path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("VAEGAN_BENCH_GRAPH", "1")),
-                    help="1: replay the iteration from one captured hipGraph (single GPU only)")
+                    help="1: replay the iteration from captured hipGraph(s); with N > 1 the graph is cut at the all-reduces")
     ap.add_argument("--elide-dead-grads", action="store_true",
                     help="skip the D weight gradients of the generator-loss pass that the reference computes and discards")
     args = ap.parse_args()
@@ -132,7 +132,7 @@ def main():
     real, ez, er, ec = (t.to(dev) for t in make_inputs(B, S, 1234 + rank))
     epoch = 60
 
-    use_graph = bool(args.graph) and world == 1
+    use_graph = bool(args.graph)            # N > 1: segmented graphs, collectives launched between the segments
     step_fn = tr.train_step_graphed if use_graph else tr.train_step
     for _ in range(max(args.warmup, 2 if use_graph else 0)):
         step_fn(real, epoch, ez, er, ec)
@@ -155,6 +155,16 @@ def main():
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+    if use_graph:
+        # graph replay: per-launch HIP events cannot be recorded inside captured graphs, so the kernel families are
+        # timed in an extra EAGER pass of the same steps after the timed region (every rank runs it: it contains
+        # the collectives; only rank 0 records)
+        timer = ops.KernelTimer() if rank == 0 else None
+        ops.set_timer(timer)
+        for _ in range(args.steps):
+            tr.train_step(real, epoch, ez, er, ec)
+        torch.cuda.synchronize()
+        ops.set_timer(None)
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -166,15 +176,6 @@ def main():
     assert all(v == v and abs(v) < 1e6 for v in ld.values()), f"non-finite losses: {ld}"
 
     # ---- roofline of the dominant kernel family (implicit-GEMM conv fprop+dgrad), measured live ----
-    if timer is None:
-        # graph replay: per-launch HIP events cannot be recorded inside the captured region, so the kernel
-        # family is timed in an extra eager pass of the same steps right after the timed region
-        timer = ops.KernelTimer()
-        ops.set_timer(timer)
-        for _ in range(args.steps):
-            tr.train_step(real, epoch, ez, er, ec)
-        torch.cuda.synchronize()
-        ops.set_timer(None)
     fam = timer.summary()
     gg = fam.get("gather_gemm", dict(launches=0, ms=1e-9, flops=0, bytes=0))
     wg = fam.get("wgrad", dict(launches=0, ms=1e-9, flops=0, bytes=0))

@@ -285,6 +285,46 @@ def test_grouped_discriminator_pass_equals_separate_passes():
         assert float((a - b).abs().max() / b.abs().max()) < 2e-3
 
 
+class _LocalReducer:
+    """world_size-1 stand-in with the GradReducer surface: lets the single GPU exercise the SEGMENTED graph path
+    (collectives between hipGraph segments) and records how the trainer drives it."""
+
+    def __init__(self):
+        self.calls = []
+
+    def reduce(self, opt):
+        self.calls.append(("reduce", id(opt)))
+        opt.flat_g.mul_(1.0)                       # an eager op on the gradient buffer between two segments
+
+    def reduce_async(self, opt):
+        self.calls.append(("async", id(opt)))
+
+    def wait(self, opt):
+        self.calls.append(("wait", id(opt)))
+
+
+def test_segmented_graph_replay_with_reducer_is_bitwise_identical_to_eager():
+    res, calls = [], []
+    for graphed in (False, True):
+        e, g, d, tr = build(64)
+        tr.reducer = _LocalReducer()
+        fn = tr.train_step_graphed if graphed else tr.train_step
+        for step in range(4):
+            real, ez, er, ec = (t.to(DEV) for t in make_inputs(4, 64, 7064 + step))
+            l = fn(real, 60, ez, er, ec)
+        res.append((l[:5].cpu().clone(), tr.opt_E.flat_p.cpu().clone(), tr.opt_G.flat_p.cpu().clone(),
+                    tr.opt_D.flat_p.cpu().clone(), float(tr.opt_D.state_dev[0])))
+        calls.append([c[0] for c in tr.reducer.calls])
+        if graphed:
+            assert len(tr._graph[1]) == 5 and len(tr._graph[2]) == 4        # 5 segments, 4 hand-offs
+    for a, b in zip(res[0][:4], res[1][:4]):
+        assert torch.equal(a, b)
+    assert res[0][4] == res[1][4] == 8.0
+    per_step = ["reduce", "reduce", "async", "reduce", "wait"]               # D, D, G (async), E, wait(G)
+    assert calls[0] == per_step * 4
+    assert calls[1] == per_step * 4                  # eager warm-up + 3 replays (capture itself runs no collective)
+
+
 def test_graph_replay_is_bitwise_identical_to_eager():
     """train_step_graphed (eager warm-up, capture, replays) == train_step, bit for bit, incl. BN counters."""
     res = []
@@ -302,6 +342,7 @@ def test_graph_replay_is_bitwise_identical_to_eager():
     for k in res[0][4]:
         assert torch.equal(res[0][4][k], res[1][4][k]), k
     assert res[0][5] == res[1][5] == (8, 8.0)
+    assert len(tr._graph[1]) == 1                    # no reducer: the whole iteration is ONE graph
 
 
 # --------------------------------------------------------------------------------------------------

@@ -37,11 +37,21 @@ class VAEGANTrainer:
         self.dt = dts.pop()
         self.latent = encoder.latent_dim
         self.losses = None
-        self._graph = None              # (key, hipGraph, static inputs, static losses)
+        self._graph = None              # (key, [hipGraph segments], [collectives between them], static in, static out)
         self._warm_key = None
+        self._cut_hook = None           # set while capturing: splits the iteration into graph segments
 
     def train(self):
         self.E.train(), self.G.train(), self.D.train()                                         # :56-58
+
+    def _cut(self, collective) -> None:
+        """A point where the iteration hands gradients to the reducer.  Eager: run the collective now.  While
+        capturing: close the current hipGraph segment, remember the collective, open the next segment -- RCCL
+        calls stay OUTSIDE the captured graphs and are launched between segment replays."""
+        if self._cut_hook is None:
+            collective()
+        else:
+            self._cut_hook(collective)
 
     def train_step(self, real: torch.Tensor, epoch: int, eps_z: Optional[torch.Tensor] = None,
                    eps_real: Optional[torch.Tensor] = None, eps_recon: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -95,7 +105,7 @@ class VAEGANTrainer:
                 D._engine.backward(c_real, dp_real, False, sink)
                 D._engine.backward(c_fake, dp_fake, False, sink)
             if self.reducer is not None:
-                self.reducer.reduce(self.opt_D)
+                self._cut(lambda: self.reducer.reduce(self.opt_D))
             self.opt_D.step()
 
         # ---- Generator + VAE loss (:110-117) ----
@@ -113,13 +123,12 @@ class VAEGANTrainer:
         d_pre = ops.nchw_grad_to_nhwc(d_recon, recon, G.padc(Gn.nc, dt), dt)
         dz = Gn._engine.backward(ctxG, d_pre, True, sink)
         if self.reducer is not None:
-            self.reducer.reduce_async(self.opt_G)                  # overlaps with the encoder's backward
+            self._cut(lambda: self.reducer.reduce_async(self.opt_G))     # overlaps with the encoder's backward
         kl_w = self.alpha_kl * min(1.0, epoch / 50)                                            # :117
         dmulv = ops.reparam_kl_backward(mulv, lvc, eps_z, dz, kl_w / B, L, dt)
         E._engine.backward(ctxE, dmulv.view(B, 1, 1, -1), False, sink)
         if self.reducer is not None:
-            self.reducer.reduce(self.opt_E)
-            self.reducer.wait(self.opt_G)
+            self._cut(lambda: (self.reducer.reduce(self.opt_E), self.reducer.wait(self.opt_G)))
         self.opt_E.step()
         self.opt_G.step()
         self.losses = losses
@@ -129,24 +138,24 @@ class VAEGANTrainer:
     def train_step_graphed(self, real: torch.Tensor, epoch: int, eps_z: Optional[torch.Tensor] = None,
                            eps_real: Optional[torch.Tensor] = None,
                            eps_recon: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Same iteration as train_step, replayed from one captured hipGraph (~400 kernel launches become one
-        graph launch).  Every call performs exactly one training iteration: the first call with a new
+        """Same iteration as train_step, replayed from captured hipGraphs (~270 kernel launches become one graph
+        launch per segment).  Every call performs exactly one training iteration: the first call with a new
         (shape, KL weight, noise mode) runs eagerly (it also sizes the workspaces), the second captures and
         replays, later calls replay.  Inputs are copied into static buffers; noise is either injected on every
         call or drawn on the device inside the graph (torch's graph-safe Philox state).
-        Not used with a gradient reducer (collectives stay eager)."""
-        if self.reducer is not None:
-            return self.train_step(real, epoch, eps_z, eps_real, eps_recon)
+        With a gradient reducer the iteration is captured as SEGMENTS that share one memory pool, cut at the points
+        where gradients are handed to the reducer; the collectives run eagerly between the segment replays (the
+        generator's all-reduce is asynchronous and overlaps the segment holding the encoder's backward)."""
         inject = eps_z is not None
         if inject and (eps_real is None or eps_recon is None):
             raise ValueError("inject all three noise tensors or none")
         key = (tuple(real.shape), float(self.alpha_kl * min(1.0, epoch / 50)), inject, self.E.training)
         if self._graph is not None and self._graph[0] == key:
-            _, g, sin, sout = self._graph
+            _, graphs, cuts, sin, sout = self._graph
             sin[0].copy_(real)
             if inject:
                 sin[1].copy_(eps_z), sin[2].copy_(eps_real), sin[3].copy_(eps_recon)
-            g.replay()
+            self._replay(graphs, cuts)
             self._advance_host_counters()
             self.losses = sout
             return sout
@@ -160,19 +169,47 @@ class VAEGANTrainer:
         torch.cuda.synchronize()
         ticks = [m._engine.pending_bn_ticks for m in (self.E, self.G, self.D)]
         steps = [o.steps for o in (self.opt_E, self.opt_G, self.opt_D)]
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            sout = self.train_step(sin[0], epoch, sin[1], sin[2], sin[3])
+        graphs, cuts = [], []
+        pool = torch.cuda.graph_pool_handle()
+        cap = torch.cuda.Stream(device=real.device)
+        cap.wait_stream(torch.cuda.current_stream())
+
+        def begin():
+            g = torch.cuda.CUDAGraph()
+            g.capture_begin(pool=pool)
+            graphs.append(g)
+
+        def cut(collective):                       # close this segment, remember the collective, open the next
+            graphs[-1].capture_end()
+            cuts.append(collective)
+            begin()
+
+        with torch.cuda.stream(cap):
+            self._cut_hook = cut
+            try:
+                begin()
+                sout = self.train_step(sin[0], epoch, sin[1], sin[2], sin[3])
+                graphs[-1].capture_end()
+            finally:
+                self._cut_hook = None
+        torch.cuda.current_stream().wait_stream(cap)
         # capture only records: undo the host-side counter changes it made, then replay for real
         for m, t in zip((self.E, self.G, self.D), ticks):
             m._engine.pending_bn_ticks = t
         for o, st in zip((self.opt_E, self.opt_G, self.opt_D), steps):
             o.steps = st
-        self._graph = (key, g, sin, sout)
-        g.replay()
+        self._graph = (key, graphs, cuts, sin, sout)
+        self._replay(graphs, cuts)
         self._advance_host_counters()
         self.losses = sout
         return sout
+
+    @staticmethod
+    def _replay(graphs, cuts) -> None:
+        for i, g in enumerate(graphs):
+            g.replay()
+            if i < len(cuts):
+                cuts[i]()
 
     def _advance_host_counters(self) -> None:
         """What one iteration does to host-side mirrors: BatchNorm forward counts (E 1, G 1, D 2*d_iters+1) and
