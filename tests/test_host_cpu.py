@@ -143,3 +143,13 @@ def test_c_abi_rejects_bad_arguments_on_host():
     w = L.WGDesc()
     assert lib.vg_wgrad_ws_bytes(ctypes.byref(w), 0) == -1
     assert lib.vg_adam_step(None, None, None, None, 0, 1e-3, 0.9, 0.999, 1e-8, 1.0, None, None) == -1
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    """No silent fallback: without libvaegan_hip.so every entry into the product raises."""
+    from importlib import import_module
+    L = import_module("vae-gan-based-model-for-image-generation-and-denoising_amd._lib")
+    monkeypatch.setattr(L, "LIB_PATH", str(tmp_path / "libvaegan_hip.so"))
+    monkeypatch.setattr(L, "_lib", None)
+    with pytest.raises(RuntimeError, match="no CPU or PyTorch fallback"):
+        L.load()

@@ -498,6 +498,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const vg_wg_desc d, i
 
 struct Plan { int tiles_kq, tiles_np, nsplit, rows_per_split, KQ, NPpad, tile; int64_t ws_bytes; };
 
+inline int wg_target() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("VG_WG_TARGET");
+        v = e ? atoi(e) : 512;
+    }
+    return v;
+}
+
 inline bool wg_use_dma(const vg_wg_desc* d) {
     static int v = -1;
     if (v < 0) {
@@ -528,7 +537,7 @@ inline int make_plan(const vg_wg_desc* d, int dtype, Plan* p) {
     p->NPpad = p->tiles_np * tile;
     const int tiles = p->tiles_kq * p->tiles_np;
     int64_t stages = (M + srows - 1) / srows;
-    int nsplit = (int)((512 + tiles - 1) / tiles);            // ~2 workgroups per CU
+    int nsplit = (int)((wg_target() + tiles - 1) / tiles);    // ~2 workgroups per CU
     // at least 8 (f32) / 4 (bf16) stages of work per workgroup, at most 1024 splits
     const int min_stages = dtype == VG_F32 ? 8 : (wg_use_dma(d) ? 8 : 4);
     if (nsplit > stages / min_stages) nsplit = (int)(stages / min_stages);

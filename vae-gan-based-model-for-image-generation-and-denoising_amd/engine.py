@@ -13,8 +13,8 @@ whenever they change.
 The nn.Module classes in nets.py wrap these chains in torch.autograd.Function objects (drop-in
 path); trainer.py drives them directly (fast path, no autograd graph).
 """
-from dataclasses import dataclass, field
-from typing import Callable, Dict, List, Optional
+from dataclasses import dataclass
+from typing import Dict, List, Optional
 
 import torch
 

@@ -13,7 +13,7 @@ Transposed convolutions (and the data gradient of strided convolutions) use the 
 decomposition: for stride 2 every output parity class (py, px) is a dense (k/2 x k/2)-tap
 convolution of the small tensor, so no zero-inserted MACs are issued.
 """
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import List, Tuple
 
 F32, BF16 = 0, 1
