@@ -293,9 +293,72 @@ __global__ __launch_bounds__(256) void gg_kernel(const vg_gg_desc d, const int k
                 }
             }
         };
+        // Fast path (every heavy layer: >= 32 bf16 channels, i.e. whole 64-byte chunks per filter tap): the pixel, its
+        // bounds test and the 64-bit source pointer are computed ONCE PER TAP; inside a tap each lane's pointer just
+        // advances by 64 bytes per chunk (0 for lanes parked on the zero page).  The ablated build showed the
+        // per-stage address generation, not the MFMAs, was the critical path of this kernel.
+        const bool fast = (upt % 4) == 0 && s_begin == 0;
+        const int nct = upt >> 2;                                      // chunks per tap
+        int tap_chunk = 0;                                             // wave-uniform
+        const unsigned char* a_cur[AP];
+        uint32_t a_stride[AP];
+        const unsigned char* b_cur[BP];
+        uint32_t b_stride[BP];
+#pragma unroll
+        for (int j = 0; j < BP; ++j) {
+            b_cur[j] = b_ok[j] ? b_ptr[j] : reinterpret_cast<const unsigned char*>(d.zeros);
+            b_stride[j] = b_ok[j] ? 64u : 0u;
+        }
+        auto issue_stage_fast = [&](int buf) {
+#pragma unroll
+            for (int c = 0; c < KCH; ++c) {
+                unsigned char* sa = smem + buf * STAGE + c * CHB;
+                unsigned char* sb = sa + BM * 64;
+                if (tap_chunk == 0) {                                  // new filter tap: the only expensive part
+                    const int dy = d.DY * ld_ta, dx = d.DX * ld_tb;
+                    const int dpix = dy * d.IW + dx;
+                    const bool tap_ok = ld_t < ntap;
+#pragma unroll
+                    for (int i = 0; i < AP; ++i) {
+                        const bool ok = tap_ok && (unsigned)(a_iy[i] + dy) < (unsigned)d.IH &&
+                                        (unsigned)(a_ix[i] + dx) < (unsigned)d.IW;
+                        a_cur[i] = ok ? Xb + ((uint32_t)(a_pix[i] + dpix) * pix_bytes + (uint32_t)q * 16u)
+                                      : reinterpret_cast<const unsigned char*>(d.zeros);
+                        a_stride[i] = ok ? 64u : 0u;
+                    }
+                }
+                const bool kin = ld_koff < wrow_bytes;                 // wave-uniform K tail (odd chunk count, KCH = 2)
+#pragma unroll
+                for (int i = 0; i < AP; ++i) {
+                    const unsigned char* g = kin ? a_cur[i] : reinterpret_cast<const unsigned char*>(d.zeros);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                     (__attribute__((address_space(3))) void*)(sa + (64 * i + 16 * wave_u) * 64),
+                                                     16, 0, 0);
+                    a_cur[i] += a_stride[i];
+                }
+#pragma unroll
+                for (int j = 0; j < BP; ++j) {
+                    const unsigned char* g = kin ? b_cur[j] : reinterpret_cast<const unsigned char*>(d.zeros);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                     (__attribute__((address_space(3))) void*)(sb + (64 * j + 16 * wave_u) * 64),
+                                                     16, 0, 0);
+                    b_cur[j] += b_stride[j];
+                }
+                ld_koff += 64;
+                if (++tap_chunk == nct) {
+                    tap_chunk = 0;
+                    ++ld_t;
+                    if (++ld_tb == d.TW) { ld_tb = 0; ++ld_ta; }
+                }
+            }
+        };
+        auto issue = [&](int buf) {
+            if (fast) issue_stage_fast(buf);
+            else issue_stage(buf);
+        };
 #pragma unroll
         for (int p = 0; p < NBUF - 1; ++p)
-            if (p < nstages) issue_stage(p);
+            if (p < nstages) issue(p);
         int rb = 0, wb = NBUF - 1;                                     // ring: read s % NBUF, write (s + NBUF-1) % NBUF
         for (int ks = 0; ks < nstages; ++ks) {
             // stages ks+1 .. ks+NBUF-2 may stay in flight; stage ks must have landed
@@ -303,7 +366,7 @@ __global__ __launch_bounds__(256) void gg_kernel(const vg_gg_desc d, const int k
             wait_vmcnt_le(ahead * LDMA);
             __builtin_amdgcn_s_barrier();
 #ifndef VG_ABLATE_LOAD
-            if (ks + NBUF - 1 < nstages) issue_stage(wb);
+            if (ks + NBUF - 1 < nstages) issue(wb);
 #endif
             compute(rb);
             rb = rb == NBUF - 1 ? 0 : rb + 1;
