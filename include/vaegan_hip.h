@@ -152,6 +152,19 @@ int vg_bn_finalize(const float* stats, int nparts, int C, int64_t count,
                    const float* gamma, const float* beta,
                    float* running_mean, float* running_var, float momentum, float eps,
                    float* mean, float* invstd, float* scale, float* shift, void* stream);
+/* Synchronised BatchNorm (statistics over the global batch of a one-process-per-GPU job).
+ * The reference is single-process (vaegan_code.py:29-35), so "the batch" of nn.BatchNorm2d is the whole batch;
+ * these three calls let N ranks reproduce that: vg_slab_sums -> host all-reduce(SUM) of the f64 [2][C] vector
+ * -> vg_bn_finalize_sums with the GLOBAL count.  Backward: vg_bn_act_backward_reduce -> vg_slab_sums ->
+ * all-reduce -> vg_bn_backward_finalize_sums (dgamma/dbeta from the LOCAL sums: the gradient all-reduce
+ * averages them afterwards; dx coefficients from the GLOBAL sums). */
+int vg_slab_sums(const float* slabs, int nparts, int C, double* sums, void* stream);
+int vg_bn_finalize_sums(const double* sums, int C, int64_t count, const float* gamma, const float* beta,
+                        float* running_mean, float* running_var, float momentum, float eps,
+                        float* mean, float* invstd, float* scale, float* shift, void* stream);
+int vg_bn_backward_finalize_sums(const double* global_sums, const double* local_sums, int C, int64_t count,
+                                 const float* gamma, const float* invstd, float* dgamma, float* dbeta,
+                                 int accumulate, float* coef, void* stream);
 /* Eval mode: scale/shift from running statistics. */
 int vg_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
                       const float* running_var, float eps, int C,

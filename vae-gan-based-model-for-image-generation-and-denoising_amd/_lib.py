@@ -72,6 +72,9 @@ SIGNATURES = {
     "vg_pack_weights": (c_int, [POINTER(PackDesc), _I, _P]),
     "vg_pack_weights_multi": (c_int, [_P, _I, _L, _I, _P]),
     "vg_bn_finalize": (c_int, [_P, _I, _I, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
+    "vg_slab_sums": (c_int, [_P, _I, _I, _P, _P]),
+    "vg_bn_finalize_sums": (c_int, [_P, _I, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
+    "vg_bn_backward_finalize_sums": (c_int, [_P, _P, _I, _L, _P, _P, _P, _P, _I, _P, _P]),
     "vg_bn_eval_coeffs": (c_int, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),
     "vg_bn_act_forward": (c_int, [_P, _P, _P, _P, _L, _I, _I, _F, _I, _L, _I, _P]),
     "vg_channel_stats": (c_int, [_P, _L, _I, _P, _I, POINTER(c_int), _I, _P]),

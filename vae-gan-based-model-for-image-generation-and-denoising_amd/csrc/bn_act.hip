@@ -158,6 +158,60 @@ __global__ __launch_bounds__(FIN_CH * FIN_PL) void bn_finalize_kernel(
     }
 }
 
+// ---- synchronised BatchNorm (one process per GPU, statistics over the GLOBAL batch) --------------------------
+// The host all-reduces the f64 [2][C] sums between these kernels (vaegan_amd ddp.py); arithmetic after the sums
+// is the same as bn_finalize_kernel / bn_bwd_finalize_kernel.
+__global__ __launch_bounds__(FIN_CH * FIN_PL) void slab_sums_kernel(const float* __restrict__ slabs, int nparts, int C,
+                                                                    double* __restrict__ sums) {
+    double s1, s2;
+    int c;
+    if (!slab_sums(slabs, nparts, C, s1, s2, c)) return;
+    sums[c] = s1;
+    sums[C + c] = s2;
+}
+
+__global__ void bn_finalize_sums_kernel(const double* __restrict__ sums, int C, double count,
+                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                        float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
+                                        float* __restrict__ mean, float* __restrict__ invstd,
+                                        float* __restrict__ scale, float* __restrict__ shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double mu = sums[c] / count;
+    double var = sums[C + c] / count - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    const float muf = (float)mu;
+    mean[c] = muf;
+    invstd[c] = is;
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float sc = g * is;
+    scale[c] = sc;
+    shift[c] = b - muf * sc;
+    if (rmean) {
+        const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * muf;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+    }
+}
+
+// dgamma/dbeta are this rank's LOCAL sums (the gradient all-reduce averages them like every other parameter
+// gradient); the dx coefficients use the GLOBAL sums and the global element count.
+__global__ void bn_bwd_finalize_sums_kernel(const double* __restrict__ gsums, const double* __restrict__ lsums, int C,
+                                            double count, const float* __restrict__ gamma,
+                                            const float* __restrict__ invstd, float* __restrict__ dgamma,
+                                            float* __restrict__ dbeta, int accumulate, float* __restrict__ coef) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float l1 = (float)lsums[c], l2 = (float)lsums[C + c];
+    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + l2 : l2;
+    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + l1 : l1;
+    const float a = (gamma ? gamma[c] : 1.f) * invstd[c];
+    coef[c] = a;
+    coef[C + c] = (float)((double)a * gsums[C + c] / count);
+    coef[2 * C + c] = (float)((double)a * gsums[c] / count);
+}
+
 __global__ void bn_eval_kernel(const float* gamma, const float* beta, const float* rmean, const float* rvar,
                                float eps, int C, float* scale, float* shift) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -306,6 +360,33 @@ extern "C" int vg_bn_finalize(const float* stats, int nparts, int C, int64_t cou
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_PL), 0, vg_stream(stream), stats, nparts, C,
                        (double)count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale,
                        shift);
+    return VG_LAUNCH_RC();
+}
+
+extern "C" int vg_slab_sums(const float* slabs, int nparts, int C, double* sums, void* stream) {
+    VG_CHECK_ARG(slabs && sums && nparts > 0 && C > 0, VG_EINVAL);
+    hipLaunchKernelGGL(slab_sums_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_PL), 0, vg_stream(stream),
+                       slabs, nparts, C, sums);
+    return VG_LAUNCH_RC();
+}
+
+extern "C" int vg_bn_finalize_sums(const double* sums, int C, int64_t count, const float* gamma, const float* beta,
+                                   float* running_mean, float* running_var, float momentum, float eps, float* mean,
+                                   float* invstd, float* scale, float* shift, void* stream) {
+    VG_CHECK_ARG(sums && C > 0 && count > 0 && mean && invstd && scale && shift, VG_EINVAL);
+    VG_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), VG_EINVAL);
+    hipLaunchKernelGGL(bn_finalize_sums_kernel, dim3((C + 255) / 256), dim3(256), 0, vg_stream(stream), sums, C,
+                       (double)count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale,
+                       shift);
+    return VG_LAUNCH_RC();
+}
+
+extern "C" int vg_bn_backward_finalize_sums(const double* global_sums, const double* local_sums, int C, int64_t count,
+                                            const float* gamma, const float* invstd, float* dgamma, float* dbeta,
+                                            int accumulate, float* coef, void* stream) {
+    VG_CHECK_ARG(global_sums && local_sums && C > 0 && count > 0 && invstd && coef, VG_EINVAL);
+    hipLaunchKernelGGL(bn_bwd_finalize_sums_kernel, dim3((C + 255) / 256), dim3(256), 0, vg_stream(stream),
+                       global_sums, local_sums, C, (double)count, gamma, invstd, dgamma, dbeta, accumulate, coef);
     return VG_LAUNCH_RC();
 }
 

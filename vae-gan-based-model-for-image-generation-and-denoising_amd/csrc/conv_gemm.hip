@@ -84,8 +84,22 @@ __global__ __launch_bounds__(256) void gg_kernel(const vg_gg_desc d, const int k
     const int wm = wave / WN, wn = wave % WN;
     const int phase = ksplit > 1 ? 0 : blockIdx.z;          // split-K launches are single-phase: z = K slice
     const int kz = ksplit > 1 ? blockIdx.z : 0;
-    const int m0 = blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
+    // XCD-aware tile order (cdna_hip_programming.md T1): workgroups are dealt round-robin over the 8 XCDs, each
+    // with a private L2.  The launch is 1-D in (m tile, n tile); id -> (xcd = id % 8, slot = id / 8) and the slots
+    // of one XCD walk ALL n tiles of an m tile before moving on, so the gathered A rows of an m tile are fetched
+    // into one XCD's L2 once and re-used by its other n tiles (speed only; any placement is correct).
+    int bx, by;
+    {
+        const int n_tiles = (d.N + BN - 1) / BN;
+        const int id = blockIdx.x;
+        const int xcd = id & 7, slot = id >> 3;
+        by = slot % n_tiles;
+        bx = (slot / n_tiles) * 8 + xcd;
+    }
+    const int m_tiles_ = (d.B * d.GH * d.GW + BM - 1) / BM;
+    if (bx >= m_tiles_) return;                             // padding blocks of the last group of 8 m tiles
+    const int m0 = bx * BM;
+    const int n0 = by * BN;
     const int M = d.B * d.GH * d.GW;
     const int GHW = d.GH * d.GW;
 
@@ -397,8 +411,8 @@ __global__ __launch_bounds__(256) void gg_kernel(const vg_gg_desc d, const int k
     // ---------------- epilogue ----------------
     if constexpr (SPLITK) {
         // split-K: raw f32 partial tile -> workspace slab [kz][Mpad][Npad]; bias/convert happen in the reduce kernel
-        const int Npad = gridDim.y * BN;
-        float* slab = d.ws + ((int64_t)kz * gridDim.x * BM + m0) * Npad + n0;
+        const int Npad = ((d.N + BN - 1) / BN) * BN;
+        float* slab = d.ws + ((int64_t)kz * m_tiles_ * BM + m0) * Npad + n0;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -478,7 +492,7 @@ __global__ __launch_bounds__(256) void gg_kernel(const vg_gg_desc d, const int k
             float a = 0.f, b = 0.f;
 #pragma unroll
             for (int w = 0; w < WM; ++w) { a += red[(w * BN + tid) * 2]; b += red[(w * BN + tid) * 2 + 1]; }
-            const int64_t part = (int64_t)phase * gridDim.x + blockIdx.x;
+            const int64_t part = (int64_t)phase * m_tiles_ + bx;
             d.stats[(part * 2 + 0) * d.N + n0 + tid] = a;
             d.stats[(part * 2 + 1) * d.N + n0 + tid] = b;
         }
@@ -623,7 +637,8 @@ template <int DT, int BM, int BN, int WM, int WN>
 int launch(const vg_gg_desc* d, hipStream_t s, SplitK sk) {
     const int M = d->B * d->GH * d->GW;
     const bool split = sk.ksplit > 1 && d->ws != nullptr && d->ws_bytes >= sk.ws_bytes;
-    dim3 grid((M + BM - 1) / BM, (d->N + BN - 1) / BN, split ? sk.ksplit : d->nphase);
+    const int m_tiles = (M + BM - 1) / BM, n_tiles = (d->N + BN - 1) / BN;
+    dim3 grid(((m_tiles + 7) / 8) * 8 * n_tiles, 1, split ? sk.ksplit : d->nphase);
     const int nstages_all = 1 << 30;
     constexpr bool CAN_DMA = (DT == VG_BF16) && (BN % 64 == 0);
     const bool dma = CAN_DMA && use_dma() && d->zeros != nullptr;
@@ -641,7 +656,7 @@ int launch(const vg_gg_desc* d, hipStream_t s, SplitK sk) {
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(splitk_reduce_kernel<DT>, dim3(blocks), dim3(256), 0, s, d->ws, sk.ksplit, M, d->N, d->OC,
-                       (int)grid.x * BM, (int)grid.y * BN, d->bias, d->Y);
+                       m_tiles * BM, n_tiles * BN, d->bias, d->Y);
     return VG_LAUNCH_RC();
 }
 

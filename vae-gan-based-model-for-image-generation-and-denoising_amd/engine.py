@@ -247,7 +247,7 @@ class StackEngine:
                 if train:
                     coeffs = ops.bn_finalize(stats, nparts, st.cout, rows, bn.weight.detach(), bn.bias.detach(),
                                              bn.running_mean, bn.running_var, BN_MOMENTUM, BN_EPS, Y.device,
-                                             groups=groups)
+                                             groups=groups, sync=self.bn_sync)
                 else:
                     coeffs = ops.bn_eval_coeffs(bn.weight.detach(), bn.bias.detach(), bn.running_mean,
                                                 bn.running_var, BN_EPS)
@@ -295,7 +295,7 @@ class StackEngine:
                 else:
                     gg_, gb_, acc_g = None, None, False
                 dY = ops.bn_act_backward(Y, dA, c["coeffs"], rows, OC, rows, st.bn.weight.detach(), st.act, st.slope,
-                                         gg_, gb_, acc_g, dt)
+                                         gg_, gb_, acc_g, dt, sync=self.bn_sync)
             elif st.act != VG_ACT_NONE:
                 dY = ops.act_backward(Y, dA, st.act, st.slope, dt)
             else:

@@ -206,12 +206,28 @@ def gather_gemm_tile_m(g: GGSpec, X, Wp, dtype: int) -> int:
     return r
 
 
-def bn_finalize(stats, nparts, C, count, gamma, beta, running_mean, running_var, momentum, eps, device, groups=1):
+def bn_finalize(stats, nparts, C, count, gamma, beta, running_mean, running_var, momentum, eps, device, groups=1,
+                sync=None):
     """-> coeffs tensor [groups][4][C]: mean, invstd, scale, shift.  With groups > 1 the slabs of group g are
     parts [g*nparts/groups, ...) and the running statistics are updated group after group (the order in which
-    the reference runs its separate forward passes)."""
+    the reference runs its separate forward passes).  sync: None, or an object with .world and
+    .all_reduce_sum(tensor) (ddp.GradReducer) -> statistics over the global batch of all ranks."""
     co = torch.empty(groups, 4, C, dtype=torch.float32, device=device)
     npg = nparts // groups
+    if sync is not None:
+        # synchronised BatchNorm: per-group f64 sums -> ONE all-reduce -> coefficients from the global sums
+        sums = torch.empty(groups, 2, C, dtype=torch.float64, device=device)
+        for g in range(groups):
+            L.check(L.load().vg_slab_sums(stats.data_ptr() + g * npg * 2 * C * 4, npg, C, sums[g].data_ptr(),
+                                          L.stream_ptr()), "vg_slab_sums")
+        sync.all_reduce_sum(sums)
+        for g in range(groups):
+            L.check(L.load().vg_bn_finalize_sums(sums[g].data_ptr(), C, (count // groups) * sync.world,
+                                                 L.ptr(gamma), L.ptr(beta), L.ptr(running_mean), L.ptr(running_var),
+                                                 momentum, eps, co[g, 0].data_ptr(), co[g, 1].data_ptr(),
+                                                 co[g, 2].data_ptr(), co[g, 3].data_ptr(), L.stream_ptr()),
+                    "vg_bn_finalize_sums")
+        return co
     for g in range(groups):
         sp = stats.data_ptr() + g * npg * 2 * C * 4
         L.check(L.load().vg_bn_finalize(sp, npg, C, count // groups, L.ptr(gamma), L.ptr(beta),
@@ -250,7 +266,7 @@ def channel_stats(x, rows, C, dtype):
     return stats, n.value
 
 
-def bn_act_backward(x, dy, coeffs, rows, C, count, gamma, act, slope, dgamma, dbeta, accumulate, dtype):
+def bn_act_backward(x, dy, coeffs, rows, C, count, gamma, act, slope, dgamma, dbeta, accumulate, dtype, sync=None):
     """Full BN(+act) backward: returns dx (gradient w.r.t. the raw conv output).  coeffs: [groups][4][C]."""
     _need_cuda(x, dy, coeffs)
     lib = L.load()
@@ -263,7 +279,20 @@ def bn_act_backward(x, dy, coeffs, rows, C, count, gamma, act, slope, dgamma, db
                                           rows, C, act, slope, partial.data_ptr(), cap, byref(n), groups, 4 * C, dtype,
                                           L.stream_ptr()), "vg_bn_act_backward_reduce")
     coef = torch.empty(groups, 3, C, dtype=torch.float32, device=x.device)
-    for g in range(groups):
+    if sync is not None:
+        lsums = torch.empty(groups, 2, C, dtype=torch.float64, device=x.device)
+        for g in range(groups):
+            L.check(lib.vg_slab_sums(partial.data_ptr() + g * n.value * 2 * C * 4, n.value, C, lsums[g].data_ptr(),
+                                     L.stream_ptr()), "vg_slab_sums")
+        gsums = lsums.clone()
+        sync.all_reduce_sum(gsums)
+        for g in range(groups):
+            L.check(lib.vg_bn_backward_finalize_sums(gsums[g].data_ptr(), lsums[g].data_ptr(), C,
+                                                     (count // groups) * sync.world, L.ptr(gamma),
+                                                     coeffs[g, 1].data_ptr(), L.ptr(dgamma), L.ptr(dbeta),
+                                                     1 if (accumulate or g > 0) else 0, coef[g].data_ptr(),
+                                                     L.stream_ptr()), "vg_bn_backward_finalize_sums")
+    for g in range(groups if sync is None else 0):
         pp = partial.data_ptr() + g * n.value * 2 * C * 4
         L.check(lib.vg_bn_backward_finalize(pp, n.value, C, count // groups, L.ptr(gamma), coeffs[g, 1].data_ptr(),
                                             L.ptr(dgamma), L.ptr(dbeta), 1 if (accumulate or g > 0) else 0,
