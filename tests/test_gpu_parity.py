@@ -434,6 +434,43 @@ def test_adam_state_dict_roundtrip_and_checkpoint_keys():
     g2.load_state_dict(g.state_dict())
 
 
+@pytest.mark.parametrize("graphed", [False, True])
+def test_checkpoint_resume_is_bitwise_identical(tmp_path, graphed):
+    """save after 2 iterations -> a FRESH trainer loads the file (weights_only) -> the next 2 iterations equal the
+    uninterrupted run bit for bit (parameters, BatchNorm buffers, Adam moments and step counts, losses)."""
+    S, B = 64, 4
+    ins = [tuple(t.to(DEV) for t in make_inputs(B, S, 700 + i)) for i in range(4)]
+
+    def run(tr, idx):
+        fn = tr.train_step_graphed if graphed else tr.train_step
+        return [fn(ins[i][0], 60, *ins[i][1:])[:5].clone() for i in idx]
+
+    e, g, d, tr = build(S)
+    run(tr, [0, 1])
+    path = str(tmp_path / "ck.pth")
+    tr.save_checkpoint(path, epoch=60)
+    la = run(tr, [2, 3])
+    e2, g2, d2, tr2 = build(S)
+    with torch.no_grad():
+        for m in (e2, g2, d2):
+            for p_ in m.parameters():
+                p_.add_(1.0)                       # make sure the load is what restores the state
+    assert tr2.load_checkpoint(path) == {"epoch": 60}
+    lb = run(tr2, [2, 3])
+    torch.cuda.synchronize()
+    for a, b in zip(la, lb):
+        assert torch.equal(a, b)
+    for ma, mb in ((e, e2), (g, g2), (d, d2)):
+        sa, sb = ma.state_dict(), mb.state_dict()
+        assert list(sa) == list(sb)
+        for k in sa:
+            assert torch.equal(sa[k], sb[k]), k
+    for oa, ob in ((tr.opt_E, tr2.opt_E), (tr.opt_G, tr2.opt_G), (tr.opt_D, tr2.opt_D)):
+        assert torch.equal(oa.exp_avg, ob.exp_avg) and torch.equal(oa.exp_avg_sq, ob.exp_avg_sq)
+        assert oa.steps == ob.steps
+    assert tr.opt_D.steps == 8 and tr.opt_E.steps == 4
+
+
 @pytest.mark.parametrize("S,sigma", [(64, 0.2), (64, 0.05), (128, 0.2)])
 def test_denoise_eval_path_vs_oracle(S, sigma):
     """BASELINE config 4 / vaegan_code.py:147-171: eval-mode E -> reparam -> G on clamp(img + sigma*eps, -1, 1),

@@ -85,6 +85,37 @@ def test_state_dict_matches_oracle_family(S):
                 assert torch.equal(sd[k], st[k].detach()), k
 
 
+def test_reference_style_checkpoint_files_interchange(tmp_path):
+    """torch.save(decoder.state_dict()) (vaegan_code.py:193) / torch.load(weights_only=True) + load_state_dict
+    (main_vae.py:246-249): files written from this package load into a torch.nn replica of the reference's module
+    tree (same keys, shapes, dtypes) and files written by that replica load into this package."""
+    e, g, d = _build(256)
+    path = str(tmp_path / "vaegan_0000_decoder.pth")
+    torch.save(g.state_dict(), path)
+    sd = torch.load(path, weights_only=True)
+    nn = torch.nn
+    layers, c = [nn.ConvTranspose2d(100, 1024, 4, 1, 0, bias=False), nn.BatchNorm2d(1024), nn.ReLU(True)], 1024
+    while c > 16:
+        layers += [nn.ConvTranspose2d(c, c // 2, 4, 2, 1, bias=False), nn.BatchNorm2d(c // 2), nn.ReLU(True)]
+        c //= 2
+    layers += [nn.ConvTranspose2d(16, 3, 3, 1, 1, bias=False), nn.Tanh()]
+
+    class RefShaped(nn.Module):                        # the reference Generator's module tree (gan_code.py:16-54)
+        def __init__(self):
+            super().__init__()
+            self.main = nn.Sequential(*layers)
+
+    ref = RefShaped()
+    ref.load_state_dict(sd)                            # strict: keys and shapes must match exactly
+    for k, v in ref.state_dict().items():
+        assert v.dtype == sd[k].dtype and torch.equal(v, sd[k])
+    with torch.no_grad():
+        ref.main[0].weight.mul_(2.0)
+    torch.save(ref.state_dict(), path)
+    g.load_state_dict(torch.load(path, weights_only=True))
+    assert torch.equal(g.main[0].weight, ref.main[0].weight)
+
+
 def test_weights_init_matches_on_class_names():
     g = V.Generator(nz=100, img_size=64)
     names = {type(m).__name__ for m in g.modules()}

@@ -7,6 +7,7 @@ vaegan_code.py:42-44), ``BCELoss`` / ``MSELoss`` (vaegan_code.py:46-47), ``confi
 (utils.py:6-14) and ``VAEGANTrainer`` (the loop body of vaegan_code.py:65-135).
 """
 from . import geometry  # noqa: F401
+from .ddp import GradReducer
 from .denoise import denoise_eval
 from .losses import BCELoss, MSELoss
 from .nets import ConvBlock, Discriminator, Encoder, Generator, weights_init
@@ -15,4 +16,4 @@ from .trainer import LOSS_NAMES, VAEGANTrainer
 from .utils import configure_seed
 
 __all__ = ["ConvBlock", "Encoder", "Generator", "Discriminator", "weights_init", "Adam", "BCELoss", "MSELoss",
-           "VAEGANTrainer", "LOSS_NAMES", "configure_seed", "geometry", "denoise_eval"]
+           "VAEGANTrainer", "LOSS_NAMES", "configure_seed", "geometry", "denoise_eval", "GradReducer"]

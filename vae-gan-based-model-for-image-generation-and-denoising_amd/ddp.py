@@ -9,8 +9,13 @@ latency-bound regime on point-to-point links.  SUM is used and the 1/world_size 
 into the Adam kernel's grad_scale, so no extra pass touches the gradients.  The generator's
 reduction is issued asynchronously and overlaps the encoder's backward (trainer.py).
 
-BatchNorm statistics stay per replica (standard DDP semantics).  Loss normalisers are per-replica
-means; with equal per-replica batches the averaged gradient equals the global-batch gradient.
+BatchNorm statistics stay per replica by default (standard DDP semantics, throughput mode).  Loss
+normalisers are per-replica means; with equal per-replica batches the averaged gradient equals the
+global-batch gradient.  VAEGANTrainer(sync_bn=True) switches every BatchNorm to statistics over the
+GLOBAL batch (forward: sum / sum-of-squares, backward: sum dy / sum dy*xhat, each one small f64
+all-reduce per layer), which makes an N-rank step equal the single-process step on the concatenated
+batch -- the reference's semantics (it is single-process) -- at the price of ~100 latency-bound
+collectives per step (parity mode; the iteration then runs eagerly, not as a replayed hipGraph).
 """
 from typing import Dict, Optional
 
@@ -27,6 +32,7 @@ class GradReducer:
         self.world = dist.get_world_size(process_group)
         self._pending: Dict[int, object] = {}
         self.bytes_reduced = 0
+        self.stat_collectives = 0
 
     def attach(self, *optimizers) -> None:
         """Fold the 1/world_size average into each optimizer's fused step."""
@@ -45,6 +51,11 @@ class GradReducer:
         w = self._pending.pop(id(opt), None)
         if w is not None:
             w.wait()
+
+    def all_reduce_sum(self, t: torch.Tensor) -> None:
+        """In-place SUM over ranks of a small statistics tensor (synchronised BatchNorm)."""
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        self.stat_collectives += 1
 
     def broadcast_parameters(self, *optimizers, src: int = 0) -> None:
         """Make every replica start from rank `src`'s weights (one broadcast per flat buffer)."""

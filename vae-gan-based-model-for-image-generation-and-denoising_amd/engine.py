@@ -102,6 +102,7 @@ class StackEngine:
         self._pack_key = None
         self._pack_ptrs = None
         self.pending_bn_ticks = 0           # num_batches_tracked increments not yet applied (flushed lazily)
+        self.bn_sync = None                 # ddp.GradReducer -> BatchNorm statistics over all ranks (SyncBN mode)
 
     # ---- geometry (cached per batch size) -----------------------------------------------------
     def spec(self, i: int, B: int, what: str):

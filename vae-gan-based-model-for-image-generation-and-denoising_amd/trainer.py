@@ -21,7 +21,8 @@ LOSS_NAMES = ("recon_loss", "kl_loss", "g_loss_adv", "d_loss_1", "d_loss_2")
 class VAEGANTrainer:
     def __init__(self, encoder, decoder, discriminator, opt_E, opt_Dec, opt_Dis, alpha_kl: float = 0.1,
                  alpha_adv: float = 0.1, noise_sigma: float = 0.05, real_label: float = 0.9, fake_label: float = 0.1,
-                 d_iters: int = 2, elide_dead_grads: bool = False, reducer=None, group_d_passes: bool = True):
+                 d_iters: int = 2, elide_dead_grads: bool = False, reducer=None, group_d_passes: bool = True,
+                 sync_bn: bool = False):
         self.E, self.G, self.D = encoder, decoder, discriminator
         self.opt_E, self.opt_G, self.opt_D = opt_E, opt_Dec, opt_Dis
         self.alpha_kl, self.alpha_adv, self.sigma = alpha_kl, alpha_adv, noise_sigma          # :49-50, :91-92
@@ -31,6 +32,13 @@ class VAEGANTrainer:
         self.elide_dead_grads = elide_dead_grads
         self.group_d_passes = group_d_passes       # run a D iteration's real+fake passes as one 2B-row launch chain
         self.reducer = reducer
+        # sync_bn: BatchNorm statistics over the global batch of all ranks (ddp.py) -- an N-rank step then equals
+        # the reference's single-process step on the concatenated batch.  Off: per-replica statistics.
+        self.sync_bn = bool(sync_bn)
+        if self.sync_bn and reducer is None:
+            raise ValueError("sync_bn=True needs a ddp.GradReducer (reducer=...)")
+        for net in (encoder, decoder, discriminator):
+            net._engine.bn_sync = reducer if self.sync_bn else None
         dts = {encoder._dt, decoder._dt, discriminator._dt}
         if len(dts) != 1:
             raise ValueError("encoder / decoder / discriminator must share one engine dtype")
@@ -149,6 +157,8 @@ class VAEGANTrainer:
         inject = eps_z is not None
         if inject and (eps_real is None or eps_recon is None):
             raise ValueError("inject all three noise tensors or none")
+        if self.sync_bn:        # a collective inside every BatchNorm: run the iteration eagerly (parity mode)
+            return self.train_step(real, epoch, eps_z, eps_real, eps_recon)
         key = (tuple(real.shape), float(self.alpha_kl * min(1.0, epoch / 50)), inject, self.E.training)
         if self._graph is not None and self._graph[0] == key:
             _, graphs, cuts, sin, sout = self._graph
@@ -221,6 +231,38 @@ class VAEGANTrainer:
         self.opt_E.steps += 1
         self.opt_G.steps += 1
         self.opt_D.steps += self.d_iters
+
+    # ---- checkpoint / resume ----------------------------------------------------------------------------------
+    # The reference only ever writes `decoder.state_dict()` (vaegan_code.py:193; main_vae.py:204-205 also the
+    # encoder) and reads such files back with torch.load(weights_only=True) + load_state_dict (main_vae.py:246-249,
+    # :356-357).  Module state_dicts here have the reference's keys/shapes/dtypes, so those files
+    # interchange both ways.  state_dict()/load_state_dict() below add what the reference lacks: all three networks
+    # plus the three Adam states in one payload of plain tensors / dicts / numbers (weights_only-loadable), from
+    # which training resumes bit-identically.
+    def state_dict(self) -> Dict:
+        return {"format": 1,
+                "encoder": self.E.state_dict(), "decoder": self.G.state_dict(), "discriminator": self.D.state_dict(),
+                "opt_E": self.opt_E.state_dict(), "opt_Dec": self.opt_G.state_dict(), "opt_Dis": self.opt_D.state_dict()}
+
+    def load_state_dict(self, sd: Dict) -> None:
+        if sd.get("format") != 1:
+            raise RuntimeError(f"unknown VAE-GAN checkpoint format {sd.get('format')!r}")
+        self.E.load_state_dict(sd["encoder"]), self.G.load_state_dict(sd["decoder"])
+        self.D.load_state_dict(sd["discriminator"])
+        self.opt_E.load_state_dict(sd["opt_E"]), self.opt_G.load_state_dict(sd["opt_Dec"])
+        self.opt_D.load_state_dict(sd["opt_Dis"])
+
+    def save_checkpoint(self, path: str, **extra) -> None:
+        """extra: plain numbers / strings / tensors stored next to the state (e.g. epoch=...)."""
+        sd = self.state_dict()
+        sd["extra"] = dict(extra)
+        torch.save(sd, path)
+
+    def load_checkpoint(self, path: str) -> Dict:
+        """Loads with torch.load(weights_only=True) (nothing in the file is executed).  Returns the extras."""
+        sd = torch.load(path, map_location=next(self.E.parameters()).device, weights_only=True)
+        self.load_state_dict(sd)
+        return sd.get("extra", {})
 
     def loss_dict(self, losses: Optional[torch.Tensor] = None, epoch: Optional[int] = None) -> Dict[str, float]:
         """Host copy of the last step's losses (one device sync, like the reference's .item() calls :125-127)."""
