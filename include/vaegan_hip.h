@@ -135,12 +135,15 @@ typedef struct vg_pack_desc {
     int32_t s_n, s_c, KW;
     int32_t kh0[VG_MAX_PHASE], kw0[VG_MAX_PHASE], kh_step, kw_step;
     int32_t tap_in_n, KHW;          /* KHW = taps of the FULL kernel (KH*KW) */
+    int32_t tile_start;             /* vg_pack_weights_multi only: first flat tile of this descriptor */
 } vg_pack_desc;
 int vg_pack_weights(const vg_pack_desc* d, int dtype, void* stream);
-/* Same, for a whole network in one launch: `descs_dev` is an array of n descriptors in DEVICE memory (their
- * src/dst pointers are stable: parameters live in the optimizer's flat buffer); max_elems = largest
- * nphase*N*Kp among them (sizes the grid). */
-int vg_pack_weights_multi(const vg_pack_desc* descs_dev, int n, int64_t max_elems, int dtype, void* stream);
+/* Same, for a whole network in one launch: `descs_dev` is an array of n <= 64 descriptors in DEVICE memory (their
+ * src/dst pointers are stable: parameters live in the optimizer's flat buffer).  The launch is one workgroup
+ * per tile: descriptor i must carry tile_start = sum of vg_pack_tile_count() of the descriptors before it, and
+ * total_tiles is the sum over all of them. */
+int vg_pack_tile_count(const vg_pack_desc* d);
+int vg_pack_weights_multi(const vg_pack_desc* descs_dev, int n, int64_t total_tiles, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * BatchNorm (train / eval) + activation, NHWC rows = B*H*W, C channels (C % 4 == 0).

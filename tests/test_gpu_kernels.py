@@ -318,8 +318,8 @@ def test_tiled_multi_pack_equals_reference_pack(ops, dtype):
         cases.append((G.linear_fprop(2, H, H, C, N, dtype)[1], w))
         cases.append((G.linear_dgrad(2, H, H, C, N, dtype)[1], w))
     outs = [torch.full((pk.numel(),), 7.0, device=DEV).to(ops.TORCH_DT[dtype]) for pk, _ in cases]
-    table = ops.pack_table([ops.pack_desc(pk, w, o) for (pk, w), o in zip(cases, outs)], DEV)
-    ops.pack_weights_multi(table, len(cases), max(pk.numel() for pk, _ in cases), dtype)
+    table, tiles = ops.pack_table([ops.pack_desc(pk, w, o) for (pk, w), o in zip(cases, outs)], DEV)
+    ops.pack_weights_multi(table, len(cases), tiles, dtype)
     for (pk, w), o in zip(cases, outs):
         ref = ops.pack_weights(pk, w, dtype)
         assert torch.equal(o, ref), pk

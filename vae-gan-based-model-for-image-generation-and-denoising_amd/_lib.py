@@ -53,7 +53,7 @@ class PackDesc(Structure):
                 ("TW", c_int32), ("Kp", c_int32),
                 ("s_n", c_int32), ("s_c", c_int32), ("KW", c_int32),
                 ("kh0", _I4), ("kw0", _I4), ("kh_step", c_int32), ("kw_step", c_int32),
-                ("tap_in_n", c_int32), ("KHW", c_int32)]
+                ("tap_in_n", c_int32), ("KHW", c_int32), ("tile_start", c_int32)]
 
 
 # name -> (restype, argtypes); every symbol include/vaegan_hip.h declares
@@ -70,6 +70,7 @@ SIGNATURES = {
     "vg_wgrad_ws_bytes": (c_int64, [POINTER(WGDesc), _I]),
     "vg_wgrad": (c_int, [POINTER(WGDesc), _I, _P]),
     "vg_pack_weights": (c_int, [POINTER(PackDesc), _I, _P]),
+    "vg_pack_tile_count": (c_int, [POINTER(PackDesc)]),
     "vg_pack_weights_multi": (c_int, [_P, _I, _L, _I, _P]),
     "vg_bn_finalize": (c_int, [_P, _I, _I, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
     "vg_slab_sums": (c_int, [_P, _I, _I, _P, _P]),

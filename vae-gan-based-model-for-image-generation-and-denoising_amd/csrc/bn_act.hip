@@ -95,13 +95,16 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const void* __restrict_
     }
 }
 
-// Sum the [nparts][2][C] partial slabs for 8 channels per workgroup: 32 "planes" of threads stride over the
-// slab rows (a one-thread-per-channel loop over up to 4096 rows is pure latency: it cost 23 % of the step),
-// double accumulation, fixed-order LDS tree -> bitwise reproducible.  Returns the sums to threads tid < 8.
-constexpr int FIN_CH = 8, FIN_PL = 32;
+// Sum the [nparts][2][C] partial slabs for 8 channels per workgroup: 128 "planes" of threads stride over the
+// slab rows (a one-thread-per-channel loop over up to 4096 rows is pure latency: it cost 23 % of the step; with
+// 32 planes these ~48 launches per iteration were still 5 us each, 6 % of it), double accumulation, then a
+// fixed-order combine (xor-shuffles over the 8 planes of a wave, LDS over the 16 waves) -> bitwise reproducible.
+// Returns the sums to threads tid < 8.
+constexpr int FIN_CH = 8, FIN_PL = 128;
 __device__ __forceinline__ bool slab_sums(const float* __restrict__ slabs, int nparts, int C, double& s1, double& s2,
                                           int& c_out) {
-    __shared__ double red[FIN_PL][FIN_CH][2];
+    constexpr int NW = FIN_CH * FIN_PL / 64;
+    __shared__ double red[NW][FIN_CH][2];
     const int cl = threadIdx.x & (FIN_CH - 1);
     const int pl = threadIdx.x / FIN_CH;
     const int c = blockIdx.x * FIN_CH + cl;
@@ -124,11 +127,16 @@ __device__ __forceinline__ bool slab_sums(const float* __restrict__ slabs, int n
             b += (double)slabs[((int64_t)p * 2 + 1) * C + c];
         }
     }
-    red[pl][cl][0] = a;
-    red[pl][cl][1] = b;
+    // a wave holds 8 planes x 8 channels (lane = 8*plane + channel): butterfly over the plane bits
+#pragma unroll
+    for (int o = FIN_CH; o < 64; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane < FIN_CH) { red[wave][lane][0] = a; red[wave][lane][1] = b; }
     __syncthreads();
     if (pl != 0 || c >= C) return false;
-    for (int k = 1; k < FIN_PL; ++k) { a += red[k][cl][0]; b += red[k][cl][1]; }
+    a = red[0][cl][0]; b = red[0][cl][1];
+#pragma unroll
+    for (int k = 1; k < NW; ++k) { a += red[k][cl][0]; b += red[k][cl][1]; }
     s1 = a; s2 = b; c_out = c;
     return true;
 }

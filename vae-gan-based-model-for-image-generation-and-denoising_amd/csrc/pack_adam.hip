@@ -44,17 +44,32 @@ __global__ void pack_kernel(const vg_pack_desc d) { pack_body<DT>(d); }
 // fastest (128-byte runs).  Each source element is read exactly once per operand.
 constexpr int PK_NT = 4, PK_CT = 64, PK_TT = 16;
 
+__host__ __device__ inline int pack_tiles(const vg_pack_desc& d) {
+    const int rowsN = d.tap_in_n ? d.N / d.KHW : d.N;
+    return ((d.IC + PK_CT - 1) / PK_CT) * ((rowsN + PK_NT - 1) / PK_NT) * ((d.KHW + PK_TT - 1) / PK_TT);
+}
+
+// One workgroup per tile over ALL descriptors of the table (flat grid: a 2-D (tile, descriptor) grid sized by the
+// largest layer launched ~50k workgroups of which most had nothing to do): descriptor i owns the flat tiles
+// [tile_start_i, tile_start_{i+1}); the owner of a tile is found with one load round + ballot over <= 64 entries.
 template <int DT>
-__global__ __launch_bounds__(256) void pack_multi_kernel(const vg_pack_desc* __restrict__ descs) {
+__global__ __launch_bounds__(256) void pack_multi_kernel(const vg_pack_desc* __restrict__ descs, int ndesc) {
     __shared__ float tile[PK_NT][PK_CT][PK_TT + 1];
-    const vg_pack_desc d = descs[blockIdx.y];
+    __shared__ int s_owner;
+    if (threadIdx.x < 64) {
+        const int ts = (int)threadIdx.x < ndesc ? descs[threadIdx.x].tile_start : 0x7fffffff;
+        const unsigned long long m = __ballot(ts <= (int)blockIdx.x);
+        if (threadIdx.x == 0) s_owner = __popcll(m) - 1;
+    }
+    __syncthreads();
+    const vg_pack_desc d = descs[s_owner];
     const int rowsN = d.tap_in_n ? d.N / d.KHW : d.N;           // rows of the source "n" index
     const int ctiles = (d.IC + PK_CT - 1) / PK_CT;
     const int ntiles = (rowsN + PK_NT - 1) / PK_NT;
     const int ttiles = (d.KHW + PK_TT - 1) / PK_TT;
     const int nblocks = ctiles * ntiles * ttiles;
     const int T = d.TH * d.TW;
-    for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+    for (int blk = (int)blockIdx.x - d.tile_start; blk < nblocks; blk += nblocks) {
         const int ct = blk % ctiles;
         const int nt = (blk / ctiles) % ntiles;
         const int tt = blk / (ctiles * ntiles);
@@ -244,15 +259,19 @@ extern "C" int vg_pack_weights(const vg_pack_desc* d, int dtype, void* stream) {
     return VG_LAUNCH_RC();
 }
 
-extern "C" int vg_pack_weights_multi(const vg_pack_desc* descs_dev, int n, int64_t max_elems, int dtype,
+extern "C" int vg_pack_tile_count(const vg_pack_desc* d) {
+    VG_CHECK_ARG(d && d->N > 0 && d->IC > 0 && d->KHW > 0, VG_EINVAL);
+    if (d->tap_in_n) VG_CHECK_ARG(d->N % d->KHW == 0, VG_EINVAL);
+    return pack_tiles(*d);
+}
+
+extern "C" int vg_pack_weights_multi(const vg_pack_desc* descs_dev, int n, int64_t total_tiles, int dtype,
                                      void* stream) {
-    VG_CHECK_ARG(descs_dev && n > 0 && n <= 65535 && max_elems > 0, VG_EINVAL);
+    VG_CHECK_ARG(descs_dev && n > 0 && n <= 64 && total_tiles > 0 && total_tiles < (1ll << 31), VG_EINVAL);
     VG_CHECK_ARG(dtype == VG_F32 || dtype == VG_BF16, VG_ENOSUP);
-    int bx = (int)((max_elems + PK_NT * PK_CT * PK_TT - 1) / (PK_NT * PK_CT * PK_TT));     // ~1 tile per block
-    if (bx > 2048) bx = 2048;
-    if (bx < 1) bx = 1;
-    if (dtype == VG_F32) hipLaunchKernelGGL(pack_multi_kernel<VG_F32>, dim3(bx, n), dim3(256), 0, vg_stream(stream), descs_dev);
-    else hipLaunchKernelGGL(pack_multi_kernel<VG_BF16>, dim3(bx, n), dim3(256), 0, vg_stream(stream), descs_dev);
+    const dim3 grid((unsigned)total_tiles);
+    if (dtype == VG_F32) hipLaunchKernelGGL(pack_multi_kernel<VG_F32>, grid, dim3(256), 0, vg_stream(stream), descs_dev, n);
+    else hipLaunchKernelGGL(pack_multi_kernel<VG_BF16>, grid, dim3(256), 0, vg_stream(stream), descs_dev, n);
     return VG_LAUNCH_RC();
 }
 

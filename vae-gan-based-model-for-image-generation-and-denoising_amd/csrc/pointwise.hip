@@ -80,9 +80,10 @@ __global__ void reparam_fwd_kernel(const void* __restrict__ mulv, const float* _
 }
 
 template <int DT>
-__global__ __launch_bounds__(256) void kl_kernel(const void* __restrict__ mulv, const float* __restrict__ lvc, int B,
-                                                 int L, int MP, float divisor, float* __restrict__ out) {
-    __shared__ double red[4];
+__global__ __launch_bounds__(1024) void kl_kernel(const void* __restrict__ mulv, const float* __restrict__ lvc, int B,
+                                                  int L, int MP, float divisor, float* __restrict__ out) {
+    // one workgroup (a single scalar result, fixed summation order); 1024 threads keep the B*L-element loop short
+    __shared__ double red[16];
     double s = 0.0;
     const int total = B * L;
     for (int i = threadIdx.x; i < total; i += blockDim.x) {
@@ -94,7 +95,11 @@ __global__ __launch_bounds__(256) void kl_kernel(const void* __restrict__ mulv, 
     s = wave_sum_d(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) out[0] = (float)(-0.5 * (red[0] + red[1] + red[2] + red[3])) / divisor;
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+        out[0] = (float)(-0.5 * t) / divisor;
+    }
 }
 
 template <int DT>
@@ -355,7 +360,7 @@ extern "C" int vg_kl_forward(const void* mulv, const float* lv_clamped, int B, i
                              int dtype, void* stream) {
     CHECK_DT();
     VG_CHECK_ARG(mulv && lv_clamped && out && B > 0 && L > 0 && MP >= 2 * L && divisor != 0.f, VG_EINVAL);
-    DISPATCH_DT(kl_kernel, dim3(1), dim3(256), vg_stream(stream), mulv, lv_clamped, B, L, MP, divisor, out);
+    DISPATCH_DT(kl_kernel, dim3(1), dim3(1024), vg_stream(stream), mulv, lv_clamped, B, L, MP, divisor, out);
     return VG_LAUNCH_RC();
 }
 

@@ -162,7 +162,7 @@ class StackEngine:
     def _build_pack_table(self, ptr_key) -> None:
         """(Re)allocate the packed operand buffers and the device-side descriptor table (pointers are stable while
         the parameters stay where they are, i.e. after the optimizer re-homed them into its flat buffer)."""
-        packs, descs, mx = {}, [], 1
+        packs, descs = {}, []
         dev = self.stages[0].conv.weight.device
         for i, st in enumerate(self.stages):
             ent = packs.setdefault(i, {})
@@ -176,9 +176,8 @@ class StackEngine:
                 _, pk = self.spec(i, 1, what)
                 ent[what] = torch.empty(pk.numel(), dtype=ops.TORCH_DT[self.dtype], device=dev)
                 descs.append(ops.pack_desc(pk, w, ent[what]))
-                mx = max(mx, pk.numel())
         self._packs, self._pack_ptrs = packs, ptr_key
-        self._pack_table, self._pack_n, self._pack_max = ops.pack_table(descs, dev), len(descs), mx
+        (self._pack_table, self._pack_max), self._pack_n = ops.pack_table(descs, dev), len(descs)
 
     def flush_bn_ticks(self) -> None:
         if self.pending_bn_ticks:

@@ -106,16 +106,25 @@ def pack_desc(pk: PackSpec, w: torch.Tensor, out: torch.Tensor) -> L.PackDesc:
                       kh_step=pk.kh_step, kw_step=pk.kw_step, tap_in_n=pk.tap_in_n, KHW=pk.KHW)
 
 
-def pack_table(descs, device) -> torch.Tensor:
-    """Descriptor table in device memory for pack_weights_multi (built once per network)."""
+def pack_table(descs, device):
+    """Descriptor table in device memory for pack_weights_multi (built once per network).
+    Returns (table, total_tiles); fills every descriptor's tile_start (flat one-workgroup-per-tile launch)."""
     import ctypes
+    lib = L.load()
+    total = 0
+    for d in descs:
+        d.tile_start = total
+        nt = lib.vg_pack_tile_count(byref(d))
+        if nt <= 0:
+            L.check(nt if nt < 0 else -1, "vg_pack_tile_count")
+        total += nt
     arr = (L.PackDesc * len(descs))(*descs)
     raw = bytes(ctypes.string_at(ctypes.addressof(arr), ctypes.sizeof(arr)))
-    return torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+    return torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device), total
 
 
-def pack_weights_multi(table: torch.Tensor, n: int, max_elems: int, dtype: int) -> None:
-    L.check(L.load().vg_pack_weights_multi(table.data_ptr(), n, max_elems, dtype, L.stream_ptr()),
+def pack_weights_multi(table: torch.Tensor, n: int, total_tiles: int, dtype: int) -> None:
+    L.check(L.load().vg_pack_weights_multi(table.data_ptr(), n, total_tiles, dtype, L.stream_ptr()),
             "vg_pack_weights_multi")
 
 
