@@ -293,7 +293,9 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const vg_wg_desc d, int
             for (int r = 0; r < 4; ++r) {
                 const int np = np0 + wnp * 64 + i * 16 + fk * 4 + r;
                 const int kq = kq0 + wkq * 64 + j * 16 + fi;
-                slab[(int64_t)np * ldk + kq] = acc[i][j][r];
+                // the reduce kernel never reads the padding of a partly used tile (narrow layers: 3-channel
+                // image operands, 32/64-channel outputs): do not spend slab bandwidth on it
+                if (np < d.NP && kq < KQ) slab[(int64_t)np * ldk + kq] = acc[i][j][r];
             }
 }
 
@@ -425,7 +427,9 @@ __global__ __launch_bounds__(256) void wgrad_bf16_dma_kernel(const vg_wg_desc d,
             for (int r = 0; r < 4; ++r) {
                 const int np = np0 + wnp * 64 + i * 16 + fk * 4 + r;
                 const int kq = kq0 + wkq * 64 + j * 16 + fi;
-                slab[(int64_t)np * ldk + kq] = acc[i][j][r];
+                // the reduce kernel never reads the padding of a partly used tile (narrow layers: 3-channel
+                // image operands, 32/64-channel outputs): do not spend slab bandwidth on it
+                if (np < d.NP && kq < KQ) slab[(int64_t)np * ldk + kq] = acc[i][j][r];
             }
 }
 
