@@ -249,6 +249,11 @@ int vg_dot_wgrad(const void* x, const float* dlogit, float* dw, int B, int K, in
  * loss[0] (+)= value when accumulate; dp[b] = gscale*(p-t)/max(p*(1-p),1e-12)/B (dp NULL ok). */
 int vg_bce_forward_backward(const float* p, float target, int B, float gscale,
                             float* loss, int accumulate, float* dp, void* stream);
+/* Sibling loop train_wgan (gan_code.py:306-315, :328): loss[0] (+)= sign*mean_b p[b]; dp[b] = sign*gscale/B. */
+int vg_mean_forward_backward(const float* p, float sign, int B, float gscale,
+                             float* loss, int accumulate, float* dp, void* stream);
+/* WGAN weight clipping `p.data.clamp_(-c, c)` (gan_code.py:320-321) over a flat parameter buffer. */
+int vg_clamp(float* p, int64_t n, float lo, float hi, void* stream);
 /* nn.MSELoss(mean) (vaegan_code.py:47) on NCHW f32 tensors; d_a = gscale*2*(a-b)/n (NULL ok). */
 int vg_mse_forward_backward(const float* a, const float* b, int64_t n, float gscale,
                             float* loss, float* d_a, float* ws, int ws_capacity, void* stream);

@@ -12,8 +12,9 @@ from .denoise import denoise_eval
 from .losses import BCELoss, MSELoss
 from .nets import ConvBlock, Discriminator, Encoder, Generator, weights_init
 from .optim import Adam
+from .siblings import DCGANTrainer, VAETrainer, WGANTrainer
 from .trainer import LOSS_NAMES, VAEGANTrainer
 from .utils import configure_seed
 
 __all__ = ["ConvBlock", "Encoder", "Generator", "Discriminator", "weights_init", "Adam", "BCELoss", "MSELoss",
-           "VAEGANTrainer", "LOSS_NAMES", "configure_seed", "geometry", "denoise_eval", "GradReducer"]
+           "VAEGANTrainer", "LOSS_NAMES", "configure_seed", "geometry", "denoise_eval", "GradReducer", "VAETrainer", "DCGANTrainer", "WGANTrainer"]

@@ -204,6 +204,31 @@ __global__ __launch_bounds__(256) void bce_kernel(const float* __restrict__ p, f
     }
 }
 
+// WGAN critic / generator losses (gan_code.py:306-315, :328): loss (+)= sign * mean(p), dp = sign * gscale / B
+__global__ __launch_bounds__(256) void mean_loss_kernel(const float* __restrict__ p, float sign, int B, float gscale,
+                                                        float* __restrict__ loss, int accumulate,
+                                                        float* __restrict__ dp) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        s += (double)p[b];
+        if (dp) dp[b] = sign * gscale / (float)B;
+    }
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float v = sign * (float)((red[0] + red[1] + red[2] + red[3]) / (double)B);
+        loss[0] = accumulate ? loss[0] + v : v;
+    }
+}
+
+// WGAN weight clipping (gan_code.py:320-321) over an optimizer's flat parameter buffer
+__global__ __launch_bounds__(256) void clamp_kernel(float* __restrict__ p, int64_t n, float lo, float hi) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        p[i] = fminf(fmaxf(p[i], lo), hi);
+}
+
 __global__ __launch_bounds__(256) void mse_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                           int64_t n, float gcoef, float* __restrict__ d_a,
                                                           float* __restrict__ ws) {
@@ -403,6 +428,19 @@ extern "C" int vg_bce_forward_backward(const float* p, float target, int B, floa
                                        float* dp, void* stream) {
     VG_CHECK_ARG(p && loss && B > 0, VG_EINVAL);
     hipLaunchKernelGGL(bce_kernel, dim3(1), dim3(256), 0, vg_stream(stream), p, target, B, gscale, loss, accumulate, dp);
+    return VG_LAUNCH_RC();
+}
+
+extern "C" int vg_mean_forward_backward(const float* p, float sign, int B, float gscale, float* loss, int accumulate,
+                                        float* dp, void* stream) {
+    VG_CHECK_ARG(p && loss && B > 0, VG_EINVAL);
+    hipLaunchKernelGGL(mean_loss_kernel, dim3(1), dim3(256), 0, vg_stream(stream), p, sign, B, gscale, loss, accumulate, dp);
+    return VG_LAUNCH_RC();
+}
+
+extern "C" int vg_clamp(float* p, int64_t n, float lo, float hi, void* stream) {
+    VG_CHECK_ARG(p && n > 0 && lo <= hi, VG_EINVAL);
+    hipLaunchKernelGGL(clamp_kernel, dim3(blocks_for(n)), dim3(256), 0, vg_stream(stream), p, n, lo, hi);
     return VG_LAUNCH_RC();
 }
 

@@ -436,6 +436,22 @@ def bce_forward_backward(p, target, gscale, loss, accumulate, want_grad, out=Non
     return dp
 
 
+def mean_forward_backward(p, sign, gscale, loss, accumulate, want_grad, out=None):
+    """loss (+)= sign*mean(p); returns dp = sign*gscale/B (WGAN losses, gan_code.py:306-315, :328)."""
+    _need_cuda(p, loss, out)
+    dp = out if out is not None else (torch.empty_like(p) if want_grad else None)
+    L.check(L.load().vg_mean_forward_backward(p.data_ptr(), sign, p.numel(), gscale, loss.data_ptr(),
+                                              1 if accumulate else 0, L.ptr(dp), L.stream_ptr()),
+            "vg_mean_forward_backward")
+    return dp
+
+
+def clamp_(flat, lo, hi):
+    """In-place clamp of a flat f32 buffer (WGAN weight clipping, gan_code.py:320-321)."""
+    _need_cuda(flat)
+    L.check(L.load().vg_clamp(flat.data_ptr(), flat.numel(), lo, hi, L.stream_ptr()), "vg_clamp")
+
+
 def mse_forward_backward(a, b, gscale, loss, want_grad):
     _need_cuda(a, b, loss)
     n = a.numel()
