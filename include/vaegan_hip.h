@@ -214,6 +214,11 @@ int vg_bias_grad(const void* dy, int64_t rows, int C, int NC, float* dbias, int 
  * instance noise out = x + sigma*eps (vaegan_code.py:91-92), eps NCHW f32 or NULL. */
 int vg_nchw_to_nhwc(const float* x, const float* eps, float sigma, void* y,
                     int B, int C, int H, int W, int CP, int dtype, void* stream);
+/* Data path (dataset_code.py:137-178): the whole image set lives in HBM as u8 [N][H][W][C] (CelebA-HQ 256x256:
+ * 5.9 GB of the 288 GB); a batch is assembled on the device from the sampler's indices with ToTensor +
+ * Normalize((0.5,),(0.5,)) arithmetic (dataset_code.py:147-150): out[b][c][h][w] = (u/255 - 0.5)/0.5, f32 NCHW. */
+int vg_gather_normalize_u8(const uint8_t* images, int64_t N, const int64_t* idx, int B, int C, int H, int W,
+                           float* out, void* stream);
 /* Denoise-evaluation input (vaegan_code.py:153-154): noisy = clamp(x + sigma*eps, lo, hi), written both as the
  * NHWC engine tensor and (optionally, y_nchw != NULL) as NCHW f32 for the caller. */
 int vg_noisy_clamp_to_nhwc(const float* x, const float* eps, float sigma, float lo, float hi, void* y,

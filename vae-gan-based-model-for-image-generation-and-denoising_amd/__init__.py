@@ -6,6 +6,7 @@ Drop-in surface (INTEGRATION.md): ``Encoder``, ``ConvBlock`` (main_vae.py:20-58)
 vaegan_code.py:42-44), ``BCELoss`` / ``MSELoss`` (vaegan_code.py:46-47), ``configure_seed``
 (utils.py:6-14) and ``VAEGANTrainer`` (the loop body of vaegan_code.py:65-135).
 """
+from . import data  # noqa: F401
 from . import geometry  # noqa: F401
 from .ddp import GradReducer
 from .denoise import denoise_eval
@@ -17,4 +18,4 @@ from .trainer import LOSS_NAMES, VAEGANTrainer
 from .utils import configure_seed
 
 __all__ = ["ConvBlock", "Encoder", "Generator", "Discriminator", "weights_init", "Adam", "BCELoss", "MSELoss",
-           "VAEGANTrainer", "LOSS_NAMES", "configure_seed", "geometry", "denoise_eval", "GradReducer", "VAETrainer", "DCGANTrainer", "WGANTrainer"]
+           "VAEGANTrainer", "LOSS_NAMES", "configure_seed", "geometry", "denoise_eval", "GradReducer", "data", "VAETrainer", "DCGANTrainer", "WGANTrainer"]

@@ -86,6 +86,7 @@ SIGNATURES = {
     "vg_act_backward": (c_int, [_P, _P, _P, _L, _I, _F, _I, _P]),
     "vg_bias_grad": (c_int, [_P, _L, _I, _I, _P, _I, _P, _I, _I, _P]),
     "vg_nchw_to_nhwc": (c_int, [_P, _P, _F, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "vg_gather_normalize_u8": (c_int, [_P, _L, _P, _I, _I, _I, _I, _P, _P]),
     "vg_noisy_clamp_to_nhwc": (c_int, [_P, _P, _F, _F, _F, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "vg_nhwc_to_nchw": (c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "vg_nchw_grad_to_nhwc": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),

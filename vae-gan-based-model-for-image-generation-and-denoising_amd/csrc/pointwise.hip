@@ -27,6 +27,27 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
     }
 }
 
+// ---- data path: batch assembly from the HBM-resident u8 dataset (dataset_code.py:137-178) ---------------------
+// images: [N][H][W][C] u8 (as the JPEG decoder leaves them), idx: B sample indices (the sampler's batch).
+// out[b][c][h][w] = (u/255 - 0.5)/0.5 : transforms.ToTensor() (float32 u / 255) followed by
+// transforms.Normalize((0.5,), (0.5,)) (x.sub(0.5).div(0.5)), dataset_code.py:147-150 -- IEEE division and
+// subtraction in that order, so the batch equals the reference's bit for bit.
+__global__ __launch_bounds__(256) void gather_u8_kernel(const uint8_t* __restrict__ images,
+                                                        const int64_t* __restrict__ idx, int64_t npix, int C, int HW,
+                                                        int64_t N, float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / HW;
+        const int64_t hw = i - b * HW;
+        int64_t n = idx[b];
+        if (n < 0 || n >= N) n = 0;                    // never read outside the dataset (host validates too)
+        const uint8_t* src = images + (n * HW + hw) * C;
+        for (int c = 0; c < C; ++c) {
+            const float t = __fdiv_rn((float)src[c], 255.0f);
+            out[(b * C + c) * HW + hw] = __fdiv_rn(__fsub_rn(t, 0.5f), 0.5f);
+        }
+    }
+}
+
 template <int DT>
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const void* __restrict__ x, float* __restrict__ y,
                                                            int64_t npix, int C, int HW, int CP, int apply_tanh) {
@@ -339,6 +360,15 @@ extern "C" int vg_nchw_to_nhwc(const float* x, const float* eps, float sigma, vo
     const int64_t npix = (int64_t)B * H * W;
     DISPATCH_DT(nchw_to_nhwc_kernel, dim3(blocks_for(npix)), dim3(256), vg_stream(stream), x, eps, sigma, y, npix, C,
                 H * W, CP, -3.0e38f, 3.0e38f, (float*)nullptr);
+    return VG_LAUNCH_RC();
+}
+
+extern "C" int vg_gather_normalize_u8(const uint8_t* images, int64_t N, const int64_t* idx, int B, int C, int H, int W,
+                                      float* out, void* stream) {
+    VG_CHECK_ARG(images && idx && out && N > 0 && B > 0 && C > 0 && H > 0 && W > 0, VG_EINVAL);
+    const int64_t npix = (int64_t)B * H * W;
+    hipLaunchKernelGGL(gather_u8_kernel, dim3(blocks_for(npix)), dim3(256), 0, vg_stream(stream), images, idx, npix, C,
+                       H * W, N, out);
     return VG_LAUNCH_RC();
 }
 

@@ -338,6 +338,20 @@ def nchw_to_nhwc(x, CP, dtype, eps=None, sigma=0.0, out=None):
     return y
 
 
+def gather_normalize_u8(images_u8, idx, out=None):
+    """images_u8 [N,H,W,C] uint8 on the device, idx [B] int64 on the device -> [B,C,H,W] f32 in [-1,1]
+    (ToTensor + Normalize(0.5,0.5), dataset_code.py:147-150)."""
+    _need_cuda(images_u8, idx, out)
+    if images_u8.dtype != torch.uint8 or idx.dtype != torch.int64 or images_u8.dim() != 4:
+        raise RuntimeError("gather_normalize_u8: images must be uint8 [N,H,W,C], idx int64 [B]")
+    N, H, W, C = images_u8.shape
+    B = idx.numel()
+    y = out if out is not None else torch.empty(B, C, H, W, dtype=torch.float32, device=images_u8.device)
+    L.check(L.load().vg_gather_normalize_u8(images_u8.data_ptr(), N, idx.data_ptr(), B, C, H, W, y.data_ptr(),
+                                            L.stream_ptr()), "vg_gather_normalize_u8")
+    return y
+
+
 def noisy_clamp_to_nhwc(x, eps, sigma, CP, dtype, lo=-1.0, hi=1.0):
     """-> (noisy NHWC engine tensor, noisy NCHW f32)."""
     _need_cuda(x, eps)
