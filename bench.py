@@ -79,6 +79,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--inject-noise", type=int, default=0,
+                    help="1: feed the three randn draws of the iteration as resident tensors (parity-test mode); "
+                         "0 (default): the iteration draws them on the device every step, as the reference does")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=int, default=64)
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch")
@@ -130,6 +133,8 @@ def main():
     tr = V.VAEGANTrainer(e, g, d, oE, oG, oD, elide_dead_grads=args.elide_dead_grads, reducer=reducer)
     tr.train()
     real, ez, er, ec = (t.to(dev) for t in make_inputs(B, S, 1234 + rank))
+    if not args.inject_noise:
+        ez = er = ec = None             # vaegan_code.py:77,91,92: randn_like on the device, inside the timed step
     epoch = 60
 
     use_graph = bool(args.graph)            # N > 1: segmented graphs, collectives launched between the segments
