@@ -14,6 +14,7 @@ The nn.Module classes in nets.py wrap these chains in torch.autograd.Function ob
 path); trainer.py drives them directly (fast path, no autograd graph).
 """
 from dataclasses import dataclass
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -23,6 +24,17 @@ from . import ops
 from ._lib import VG_ACT_LRELU, VG_ACT_NONE, VG_ACT_RELU
 
 BN_MOMENTUM, BN_EPS = 0.1, 1e-5       # nn.BatchNorm2d defaults (main_vae.py:24, gan_code.py:22)
+
+_SIDE = {}
+
+
+def side_stream(device) -> "torch.cuda.Stream":
+    """One low-priority stream per device for work that is off the critical path of a backward pass."""
+    key = str(device)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device, priority=0)
+    return _SIDE[key]
+
 
 def bump_weights_epoch(params) -> None:
     """Called by optim.Adam after it rewrote `params` behind torch's back (raw-pointer kernel): packed operand
@@ -103,6 +115,12 @@ class StackEngine:
         self._pack_ptrs = None
         self.pending_bn_ticks = 0           # num_batches_tracked increments not yet applied (flushed lazily)
         self.bn_sync = None                 # ddp.GradReducer -> BatchNorm statistics over all ranks (SyncBN mode)
+        # Weight/bias gradients of a stage feed nothing downstream in the backward pass: launched on a side stream
+        # they could overlap the latency-bound BatchNorm-backward chain (reduce -> finalize -> apply, ~25 us of
+        # 5-10 us kernels) of the next stage.  MEASURED SLOWER on MI355X (S=64, B=128: 34.0k vs 35.9k img/s; with
+        # a high-priority main stream 17.5k): the concurrent wgrad and dgrad grids evict each other's L2/LDS
+        # residency and the small kernels queue behind full CUs.  Kept as an opt-in experiment (VG_SIDE_WGRAD=1).
+        self.side_wgrad = os.environ.get("VG_SIDE_WGRAD", "0") == "1"
 
     # ---- geometry (cached per batch size) -----------------------------------------------------
     def spec(self, i: int, B: int, what: str):
@@ -274,6 +292,8 @@ class StackEngine:
         packs = self._ensure_packed()
         dt = self.dtype
         dA = dout
+        side = side_stream(dout.device) if (self.side_wgrad and param_grads) else None
+        held = []                           # tensors the side stream reads: kept alive until the join
         for i in range(len(self.stages) - 1, -1, -1):
             st, c = self.stages[i], ctx[i]
             want_dx = need_dx or i > 0
@@ -301,13 +321,22 @@ class StackEngine:
             else:
                 dY = dA
             if param_grads:
-                self._param_grads(i, st, c, dY, B, rows, OC, sink)
+                if side is None:
+                    self._param_grads(i, st, c, dY, B, rows, OC, sink)
+                else:
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        self._param_grads(i, st, c, dY, B, rows, OC, sink)
+                    held.append(dY)
             if want_dx:
                 ggd, _ = self.spec(i, B, "dgrad")
                 dX, _, _ = ops.gather_gemm(ggd, dY, packs[i]["dgrad"], dt, alg=st.alg(B, dt))
                 dA = dX.view(c["x"].shape)
             else:
                 dA = None
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+            held.clear()
         return dA
 
     def _param_grads(self, i, st, c, dY, B, rows, OC, sink):

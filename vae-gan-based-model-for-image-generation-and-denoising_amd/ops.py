@@ -323,7 +323,7 @@ def act_backward(x, dy, act, slope, dtype):
 
 def bias_grad(dy, rows, C, NC, dbias, accumulate, dtype):
     cap = 1024
-    ws = WS.get("bnbwd", cap * 2 * C * 4, dy.device)
+    ws = WS.get("biasgrad", cap * 2 * C * 4, dy.device)      # own buffer: may run on the side stream
     L.check(L.load().vg_bias_grad(dy.data_ptr(), rows, C, NC, dbias.data_ptr(), 1 if accumulate else 0,
                                   ws.data_ptr(), cap, dtype, L.stream_ptr()), "vg_bias_grad")
 
