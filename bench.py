@@ -135,6 +135,7 @@ def main():
     real, ez, er, ec = (t.to(dev) for t in make_inputs(B, S, 1234 + rank))
     if not args.inject_noise:
         ez = er = ec = None             # vaegan_code.py:77,91,92: randn_like on the device, inside the timed step
+        torch.cuda.manual_seed(4242 + rank)     # identical weights on every rank (seed 42), different noise streams
     epoch = 60
 
     use_graph = bool(args.graph)            # N > 1: segmented graphs, collectives launched between the segments
