@@ -451,7 +451,8 @@ def test_adam_state_dict_roundtrip_and_checkpoint_keys():
     g2.load_state_dict(g.state_dict())
 
 
-def test_graph_replay_draws_fresh_device_noise():
+@pytest.mark.parametrize("segmented", [False, True])
+def test_graph_replay_draws_fresh_device_noise(segmented):
     """Without injected noise the three randn draws of the iteration (vaegan_code.py:77,91,92) are made on the
     device inside the captured graph; every replay must see NEW noise (graph-safe Philox offsets), and the same
     seed must give the same sequence again.  lr = 0 keeps the weights fixed, so only the noise moves the losses."""
@@ -459,6 +460,8 @@ def test_graph_replay_draws_fresh_device_noise():
     runs = []
     for _ in range(2):
         e, g, d, tr = build(64, lr=0.0)
+        if segmented:                                   # the N>1 shape of the iteration: 5 hipGraph segments
+            tr.reducer = _LocalReducer()
         torch.manual_seed(123)
         torch.cuda.manual_seed(123)
         runs.append(torch.stack([tr.train_step_graphed(real, 60)[:5].clone() for _ in range(5)]).cpu())
