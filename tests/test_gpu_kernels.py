@@ -323,3 +323,60 @@ def test_tiled_multi_pack_equals_reference_pack(ops, dtype):
     for (pk, w), o in zip(cases, outs):
         ref = ops.pack_weights(pk, w, dtype)
         assert torch.equal(o, ref), pk
+
+
+# ---- patch gather-GEMM (csrc/conv_patch.hpp): the tile's input patch resident in LDS, taps read it shifted ----------
+PATCH_CASES = [  # kind, B, H (input), Cin, Cout      (k4 s2 p1 everywhere; all give M % 256 == 0)
+    ("conv", 8, 32, 64, 128), ("conv", 2, 64, 32, 128), ("conv", 8, 16, 128, 256), ("conv", 4, 32, 96, 160),
+    ("convT", 8, 16, 128, 128), ("convT", 2, 32, 64, 128), ("convT", 8, 8, 256, 256), ("convT", 4, 16, 96, 160),
+    ("conv_dgrad", 8, 32, 128, 64), ("conv_dgrad", 4, 16, 256, 96),          # transposed form, N = Cin
+    ("convT_dgrad", 8, 16, 128, 128), ("convT_dgrad", 4, 8, 160, 64),        # direct stride-2 form, N = Cin
+]
+
+
+@pytest.mark.parametrize("kind,B,H,Cin,Cout", PATCH_CASES)
+@pytest.mark.parametrize("variant", ["patch128", "patch256"])
+def test_patch_gather_gemm_equals_reference_and_gather_path(ops, monkeypatch, kind, B, H, Cin, Cout, variant):
+    """Both patch forms (one phase of the 4-phase transposed form; the stride-2 4x4 conv as 4 input-parity classes),
+    4-wave 128-row and 8-wave 256-row tiles, against torch fp64 and against the per-tap gather kernel."""
+    dtype = G.BF16
+    g = torch.Generator().manual_seed(H * 7 + Cin)
+    if kind == "conv":
+        x = _q(torch.randn(B, Cin, H, H, generator=g), dtype)
+        w = torch.randn(Cout, Cin, 4, 4, generator=g) * 0.1
+        ref = F.conv2d(x, _q(w, dtype), None, stride=2, padding=1)
+        gg, pk = G.conv_fprop(B, H, H, Cin, Cout, 4, 2, 1, dtype)
+        nout = Cout
+    elif kind == "convT":
+        x = _q(torch.randn(B, Cin, H, H, generator=g), dtype)
+        w = torch.randn(Cin, Cout, 4, 4, generator=g) * 0.1
+        ref = F.conv_transpose2d(x, _q(w, dtype), None, stride=2, padding=1)
+        gg, pk = G.convT_fprop(B, H, H, Cin, Cout, 4, 2, 1, dtype)
+        nout = Cout
+    elif kind == "conv_dgrad":                       # dx of Conv2d(Cin -> Cout) on an H x H input; operand = dy
+        x = _q(torch.randn(B, Cout, H // 2, H // 2, generator=g), dtype)
+        w = torch.randn(Cout, Cin, 4, 4, generator=g) * 0.1
+        ref = torch.nn.grad.conv2d_input((B, Cin, H, H), _q(w, dtype), x, stride=2, padding=1)
+        gg, pk = G.conv_dgrad(B, H, H, Cin, Cout, 4, 2, 1, dtype)
+        nout = Cin
+    else:                                            # dx of ConvTranspose2d(Cin -> Cout) on an H x H input; operand = dy
+        x = _q(torch.randn(B, Cout, 2 * H, 2 * H, generator=g), dtype)
+        w = torch.randn(Cin, Cout, 4, 4, generator=g) * 0.1
+        ref = F.conv2d(x, _q(w, dtype), None, stride=2, padding=1)          # dgrad of convT == conv with the same weights
+        gg, pk = G.convT_dgrad(B, H, H, Cin, Cout, 4, 2, 1, dtype)
+        nout = Cin
+    Wp = ops.pack_weights(pk, w.to(DEV), dtype)
+    X = _dev(to_nhwc(x, gg.IC), dtype, ops)
+    monkeypatch.setenv("VG_TILE_MIN_WGS", "1")       # small problems still take the 128 x 128 tile
+    outs = {}
+    for mode in ("gather", variant):
+        monkeypatch.setenv("VG_GG_PATCH", "0" if mode == "gather" else "1")
+        monkeypatch.setenv("VG_PATCH256_MIN", "1" if mode == "patch256" else "2000000000")
+        Y, st, nparts = ops.gather_gemm(gg, X, Wp, dtype, want_stats=True)
+        M = gg.B * gg.GH * gg.GW
+        assert nparts == gg.nphase * (M // (256 if mode == "patch256" else 128))
+        outs[mode] = (from_nhwc(Y.double().cpu(), nout), st[: nparts * 2 * nout].view(nparts, 2, nout).double().sum(0).cpu())
+    close(outs[variant][0], ref, dtype)
+    # same products, different summation order (class/chunk/tap instead of tap/chunk): bf16 output rounding apart
+    close(outs[variant][0], outs["gather"][0], dtype)
+    torch.testing.assert_close(outs[variant][1], outs["gather"][1], rtol=1e-5, atol=1e-3)

@@ -216,6 +216,8 @@ __global__ __launch_bounds__(256) void gg_kernel(const vg_gg_desc d, const int k
 
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
+    // (an explicit ds_read / MFMA scheduling pipeline -- __builtin_amdgcn_sched_group_barrier, next chunk's reads
+    // between this chunk's MFMAs -- was measured here and changes nothing: the loop waits on DMA arrival, not on LDS)
     auto compute = [&](int buf) {
 #ifdef VG_ABLATE_COMPUTE
         return;
@@ -553,6 +555,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
+#include "conv_patch.hpp"
+
 struct TileCfg { int bm, bn; };
 struct SplitK { int ksplit, sps; int64_t ws_bytes; };
 
@@ -569,24 +573,29 @@ inline bool use_dma() {
     return v != 0;
 }
 
-inline int min_wgs() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("VG_TILE_MIN_WGS");
-        v = e ? atoi(e) : 512;
-    }
-    return v;
+inline int min_wgs() {                      // read per call (a few hundred ns): tests flip it inside one process
+    const char* e = getenv("VG_TILE_MIN_WGS");
+    return e ? atoi(e) : 512;
 }
 
 // (a 256x128 tile -- wave tile 128x64, 152 VGPRs, one wave per SIMD -- was measured and loses on every layer)
+inline int patch256_min() {
+    const char* e = getenv("VG_PATCH256_MIN");
+    return e ? atoi(e) : 0x7fffffff;        // the 8-wave patch variant is opt-in (measured slower, conv_patch.hpp)
+}
+
 inline TileCfg pick_tile(const vg_gg_desc* d, bool bf16 = false) {
-    (void)bf16;
     const int M = d->B * d->GH * d->GW;
     const int N = d->N;
     const int ph = d->nphase;
     const int need = min_wgs();
     if (N <= 16) return {256, 16};
     if (N <= 32) return {128, 32};
+    // 256 x 128 exists only as the patch kernel (bf16, LDS-DMA): 8 waves share every weight tile
+    PatchGeo pg;
+    if (bf16 && N > 64 && use_patch() && use_dma() && d->zeros != nullptr &&
+        tiles_of(M, N, 256, 128) * ph >= patch256_min() && patch_geometry(d, 256, &pg))
+        return {256, 128};
     if (N > 64 && tiles_of(M, N, 128, 128) * ph >= need) return {128, 128};
     if (tiles_of(M, N, 128, 64) * ph >= need) return {128, 64};
     return {64, 64};
@@ -701,5 +710,15 @@ extern "C" int vg_gather_gemm(const vg_gg_desc* d, int dtype, void* stream) {
         VG_CHECK_ARG(d->stats_capacity >= d->nphase * ((M + t.bm - 1) / t.bm), VG_EINVAL);
     }
     if (dtype == VG_F32) return dispatch<VG_F32>(d, t, vg_stream(stream), sk);
+    PatchGeo pg;
+    if ((t.bm == 128 || t.bm == 256) && t.bn == GP_BN && sk.ksplit <= 1 && use_patch() && use_dma() &&
+        d->zeros != nullptr && patch_geometry(d, t.bm, &pg)) {
+        const int m_tiles = (d->B * d->GH * d->GW) / t.bm, n_tiles = (d->N + GP_BN - 1) / GP_BN;
+        dim3 grid(((m_tiles + 7) / 8) * 8 * n_tiles, 1, d->nphase);
+        if (t.bm == 256) vg_launch_timed(0, ggp_kernel<4>, grid, dim3(512), 0, vg_stream(stream), *d, pg);
+        else vg_launch_timed(0, ggp_kernel<2>, grid, dim3(256), 0, vg_stream(stream), *d, pg);
+        return VG_LAUNCH_RC();
+    }
+    if (t.bm == 256 && t.bn == 128) return VG_EINVAL;      // (env flipped between planning and launch)
     return dispatch<VG_BF16>(d, t, vg_stream(stream), sk);
 }

@@ -1,0 +1,367 @@
+// Patch gather-GEMM: the 2x2-tap / stride-2 4x4-tap convolution forms with the input patch of a tile resident in LDS.
+// Included by conv_gemm.hip (inside its anonymous namespace).  bf16, LDS-DMA, 128 x 128 (4 waves) or 256 x 128
+// (8 waves) output tile.
+//
+// Why.  gg_kernel re-gathers the A operand once per filter tap: a 128-row tile moves 4 x 128 pixels x 64 B per
+// 32-channel chunk for a 2x2-tap form although those rows are the SAME input pixels shifted by one.  The kernel
+// sits on the per-CU L2->LDS fill rate, so bytes per FLOP are what bounds it.  Here a tile's
+// input patch -- (R+1) x (GW+1) pixels for R whole grid rows -- is fetched ONCE per 32-channel chunk (<= 192 pixels
+// instead of 512) and the four taps read it at four shifted positions; only the weight tiles still stream per tap.
+// LDS fill per (chunk, 4 taps): <= 12 KB patch + 32 KB weights, against 32 + 32 KB.
+//
+// Forms (vg_gg_desc):
+//   * one phase of the 4-phase transposed form: TH = TW = 2, SY = SX = 1, DY, DX = +-1 (blockIdx.z = phase);
+//   * the direct stride-2 4x4 convolution: TH = TW = 4, SY = SX = 2, DY = DX = 1, split into its 4 input-parity
+//     classes, each of which IS a 2x2-tap stride-1 form on the parity-subsampled input.
+// Tile = 128 consecutive grid pixels = IMGS images x R whole grid rows (GW a power of two <= 64).
+//
+// Pipeline per workgroup: chunks j = (class, 32-channel chunk); patch(j) lives in pbuf[j & 1] and is fetched while
+// chunk j-1 is multiplied (3 DMA rounds, one per tap stage); weight tiles ride a 3-deep ring, 2 stages ahead, exactly
+// as in gg_kernel.  One s_barrier per tap stage, counted s_waitcnt vmcnt (all DMA of a wave completes in order).
+
+struct PatchGeo {
+    int R, IMGS, PW, PIMG, NPP;     // grid rows per image in a tile, images per tile, patch width, pixels per image, total
+    int ncy, ncx, nct;              // parity classes per dimension, 32-channel chunks per (class, tap)
+};
+
+constexpr int GP_BN = 128, GP_BST = GP_BN * 64, GP_NB = 3;
+
+__device__ __forceinline__ void gp_wait(int n) {
+    if (n >= 3) VG_WAITCNT_VM(3);
+    else if (n == 2) VG_WAITCNT_VM(2);
+    else if (n == 1) VG_WAITCNT_VM(1);
+    else VG_WAITCNT_VM(0);
+}
+
+// WM = 2: 128-row tile, 4 waves, patch <= 192 pixels, 48.5 KB LDS (3 workgroups per CU).
+// WM = 4: 256-row tile, 8 waves sharing every weight tile (half the weight traffic per FLOP), patch <= 384 pixels,
+//         73 KB LDS (2 workgroups = 16 waves per CU -> 128 registers per wave).  MEASURED SLOWER than WM = 2 on
+//         MI355X (G3 dgrad 542 vs 800, G4 dgrad 553 vs 747 TFLOP/s): the register cap spills (36 dwords) and drops
+//         the hoisted fragment addresses.  Kept selectable (VG_PATCH256_MIN=<min tiles>) as the starting point for a
+//         leaner 8-wave kernel; never chosen by default.
+template <int WM>
+__global__ __launch_bounds__(128 * WM, WM == 4 ? 4 : 1) void ggp_kernel(const vg_gg_desc d, const PatchGeo g) {
+    constexpr int BM = 64 * WM, BN = GP_BN, WN = 2, TM = 4, TN = 4, NT = 128 * WM;
+    constexpr int GP_PBUF = 3 * NT * 16;            // 3 DMA rounds of NT lanes x 16 B
+    constexpr int BJ = 512 / NT;                    // weight-tile DMA instructions per wave and stage (2 / 1)
+    // [patch buffers 2 x 12|24 KB][weight ring 3 x 8 KB][output-pixel table]
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * GP_PBUF + GP_NB * GP_BST + BM * 4];
+    unsigned char* const pbuf = smem;
+    unsigned char* const bring = smem + 2 * GP_PBUF;
+    int* const opix_tab = reinterpret_cast<int*>(smem + 2 * GP_PBUF + GP_NB * GP_BST);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int wm = wave / WN, wn = wave % WN;
+    const int phase = blockIdx.z;
+    int bx, by;
+    {
+        const int n_tiles = (d.N + BN - 1) / BN;
+        const int id = blockIdx.x;
+        const int xcd = id & 7, slot = id >> 3;
+        by = slot % n_tiles;
+        bx = (slot / n_tiles) * 8 + xcd;
+    }
+    const int M = d.B * d.GH * d.GW;
+    const int GHW = d.GH * d.GW;
+    const int m_tiles_ = M / BM;                               // eligibility: M % 128 == 0
+    if (bx >= m_tiles_) return;
+    const int m0 = bx * BM, n0 = by * BN;
+    const int b0 = m0 / GHW;
+    const int gy0 = (m0 - b0 * GHW) / d.GW;                    // 0 for multi-image tiles
+
+    const unsigned char* Xb = reinterpret_cast<const unsigned char*>(d.X);
+    const unsigned char* Wb = reinterpret_cast<const unsigned char*>(d.W);
+    const unsigned char* Zp = reinterpret_cast<const unsigned char*>(d.zeros);
+    const uint32_t pix_bytes = (uint32_t)d.IC * 2u;
+    const uint32_t wrow_bytes = (uint32_t)d.Kp * 2u;
+    const int ncls = g.ncy * g.ncx;
+    const int J = ncls * g.nct;                                 // chunks
+    const int S = J * 4;                                        // tap stages
+
+    // ---- weight-tile DMA lanes: rows lrow, lrow + 64; source unit swizzled by the row (as gg_kernel) ----
+    const int lrow = tid >> 2;
+    const int qb = (tid & 3) ^ ((-(lrow >> 2)) & 3);
+    const unsigned char* b_base[BJ];
+    uint32_t b_live[BJ];
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+        const int n = n0 + lrow + (NT / 4) * j;
+        const bool ok = n < d.N;
+        b_base[j] = ok ? Wb + ((int64_t)phase * d.N + n) * wrow_bytes + qb * 16 : Zp;
+        b_live[j] = ok ? 1u : 0u;
+    }
+    // ---- patch DMA lanes: LDS slot sidx = NT*r + tid -> pixel pp = sidx >> 2, stored unit sidx & 3.  The lane's
+    // pixel coordinates are recomputed at every class change (<= 4 times per kernel) rather than kept in registers.
+    const unsigned char* a_cur[3];
+    uint32_t a_live = 0;                                         // bit r: round r reads real data (else the zero page)
+    auto patch_sources = [&](int cl) {
+        const int py = cl / g.ncx, px = cl - py * g.ncx;
+        // class (py, px): input pixel of patch position (pr, pc) is ((gy0 + pr)*SY + cy, pc*SX + cx)
+        const int cy = d.y0[phase] + d.DY * py - (d.DY < 0 ? d.SY : 0);
+        const int cx = d.x0[phase] + d.DX * px - (d.DX < 0 ? d.SX : 0);
+        a_live = 0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int sidx = NT * r + tid;
+            const int pp = sidx >> 2;
+            const int q = (sidx & 3) ^ ((-(pp >> 2)) & 3);
+            const int img = pp / g.PIMG;
+            const int rem = pp - img * g.PIMG;
+            const int pr = rem / g.PW;
+            const int pc = rem - pr * g.PW;
+            const int b = b0 + img;
+            const int iy = (gy0 + pr) * d.SY + cy;
+            const int ix = pc * d.SX + cx;
+            const bool ok = pp < g.NPP && b < d.B && (unsigned)iy < (unsigned)d.IH && (unsigned)ix < (unsigned)d.IW;
+            a_cur[r] = ok ? Xb + ((uint32_t)((b * d.IH + iy) * d.IW + ix) * pix_bytes + (uint32_t)q * 16u) : Zp;
+            a_live |= ok ? (1u << r) : 0u;
+        }
+    };
+    // issue-side cursors
+    int pj_cl = 0, pj_c = 0;                                    // (class, chunk) of the NEXT patch to fetch
+    auto issue_patch_round = [&](int buf, int r) {              // r is a compile-time constant at every call site
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a_cur[r],
+                                         (__attribute__((address_space(3))) void*)(pbuf + buf * GP_PBUF + (NT * r + 64 * wave_u) * 16),
+                                         16, 0, 0);
+        a_cur[r] += (a_live >> r & 1u) * 64u;
+    };
+    auto patch_advance = [&]() {                                // after the 3 rounds of one patch
+        if (++pj_c == g.nct) { pj_c = 0; ++pj_cl; if (pj_cl < ncls) patch_sources(pj_cl); }
+    };
+    int bs_cl = 0, bs_c = 0, bs_k = 0;                          // (class, chunk, tap-in-class) of the NEXT weight stage
+    auto issue_b = [&](int buf) {
+        const int py = bs_cl / g.ncx, px = bs_cl - py * g.ncx;
+        const int t = ((bs_k >> 1) * g.ncy + py) * d.TW + ((bs_k & 1) * g.ncx + px);
+        const uint32_t koff = ((uint32_t)t * (uint32_t)d.IC + (uint32_t)bs_c * 32u) * 2u;
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) {
+            const unsigned char* src = b_base[j] + (b_live[j] ? koff : 0u);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(bring + buf * GP_BST + ((NT / 4) * j + 16 * wave_u) * 64),
+                                             16, 0, 0);
+        }
+        if (++bs_k == 4) { bs_k = 0; if (++bs_c == g.nct) { bs_c = 0; ++bs_cl; } }
+    };
+
+    // ---- fragment addressing ----
+    const int fr = lane & 15, fg = lane >> 4;
+    int ppbase[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int r = wm * 64 + i * 16 + fr;
+        const int per_img = g.R * d.GW;
+        const int img = r / per_img;
+        const int rr = r - img * per_img;
+        const int ry = rr / d.GW;
+        ppbase[i] = img * g.PIMG + ry * g.PW + (rr - ry * d.GW);
+    }
+    const int sh_y1 = d.DY > 0 ? 1 : 0, sh_x1 = d.DX > 0 ? 1 : 0;   // patch shift of local tap a = 1 (a = 0: the other)
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](int pb, int bb, int k) {
+        const int a = k >> 1, b = k & 1;
+        const int shy = a ? sh_y1 : 1 - sh_y1, shx = b ? sh_x1 : 1 - sh_x1;
+        int tapoff = shy * g.PW + shx;
+        if constexpr (WM == 4) {
+            // 8-wave variant only: keep the four taps' fragment addresses from being hoisted out of the chunk loop
+            // (16 address VGPRs live across the whole kernel spill under its 128-register cap).  The 4-wave variant
+            // WANTS them hoisted: recomputing them per stage cost it 10 %.
+            asm volatile("" : "+s"(tapoff));
+        }
+        const unsigned char* sa = pbuf + pb * GP_PBUF;
+        const unsigned char* sb = bring + bb * GP_BST;
+        u32x4 fa[TM], fb[TN];
+        auto ld_a = [&](int i) {
+            const int pp = ppbase[i] + tapoff;
+            fa[i] = *reinterpret_cast<const u32x4*>(sa + pp * 64 + ((fg ^ ((-(pp >> 2)) & 3)) << 4));
+        };
+        auto ld_b = [&](int j) {
+            const int r = wn * 64 + j * 16 + fr;
+            fb[j] = *reinterpret_cast<const u32x4*>(sb + r * 64 + ((fg ^ ((-(r >> 2)) & 3)) << 4));
+        };
+        ld_a(0); ld_b(0); ld_b(1); ld_a(1); ld_b(2); ld_a(2); ld_b(3); ld_a(3);
+#define GP_MFMA(i, j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]), \
+                                                                  __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0)
+        // MFMAs in the order their fragments arrive (fa0 fb0 | fb1 | fa1 | fb2 | fa2 | fb3 | fa3) ...
+        GP_MFMA(0, 0);
+        GP_MFMA(0, 1);
+        GP_MFMA(1, 0); GP_MFMA(1, 1);
+        GP_MFMA(0, 2); GP_MFMA(1, 2);
+        GP_MFMA(2, 0); GP_MFMA(2, 1); GP_MFMA(2, 2);
+        GP_MFMA(0, 3); GP_MFMA(1, 3); GP_MFMA(2, 3);
+        GP_MFMA(3, 0); GP_MFMA(3, 1); GP_MFMA(3, 2); GP_MFMA(3, 3);
+#undef GP_MFMA
+#ifndef VG_NO_SCHED
+        // ... and a scheduling pipeline that interleaves the ds_read_b128s with them instead of "all reads, wait for
+        // everything, all MFMAs" (0x100 = DS read, 0x008 = MFMA)
+        // two reads stay in flight ahead of the MFMA that needs them (counted lgkmcnt waits, no drain)
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 10, 0);
+#endif
+    };
+
+    // ---- prologue: patch(0) (3 rounds), weight stages 0 and 1 ----
+    patch_sources(0);
+    issue_patch_round(0, 0);
+    issue_patch_round(0, 1);
+    issue_patch_round(0, 2);
+    patch_advance();
+    issue_b(0);
+    issue_b(1);
+    // ---- main loop over chunks; the 4 tap stages of a chunk are unrolled (static DMA counts per stage) ----
+    int bb = 0, wb = 2, s = 0;
+    for (int j = 0; j < J; ++j) {
+        const int pb = j & 1;
+        const bool more_p = j + 1 < J;
+#pragma unroll
+        for (int k = 0; k < 4; ++k, ++s) {
+            // in flight behind weight stage s: what stage s-1 issued = [one patch round (k = 1, 2, 3)] + [stage s+1]
+            const bool tail = s + 1 >= S;
+            gp_wait(tail ? 0 : (k == 0 ? BJ : (more_p ? BJ + 1 : BJ)));
+            __builtin_amdgcn_s_barrier();
+            if (k < 3 && more_p) {
+                if (k == 0) issue_patch_round(pb ^ 1, 0);
+                else if (k == 1) issue_patch_round(pb ^ 1, 1);
+                else { issue_patch_round(pb ^ 1, 2); patch_advance(); }
+            }
+            if (s + 2 < S) issue_b(wb);
+            compute(pb, bb, k);
+            bb = bb == GP_NB - 1 ? 0 : bb + 1;
+            wb = wb == GP_NB - 1 ? 0 : wb + 1;
+        }
+    }
+
+    // ---------------- epilogue (as gg_kernel<bf16, 128, 128>) ----------------
+    typedef ElemT<VG_BF16> E;
+    constexpr int ESZ = 2;
+    const bool flat = (d.nphase == 1 && d.OSY == 1 && d.OSX == 1 && d.GH == d.OH && d.GW == d.OW);
+    for (int r = tid; r < BM; r += NT) {
+        const int m = m0 + r;
+        int op = -1;
+        if (m < M) {
+            if (flat) {
+                op = m;
+            } else {
+                const int b = m / GHW;
+                const int rem = m - b * GHW;
+                const int gy = rem / d.GW;
+                const int gx = rem - gy * d.GW;
+                const int oy = gy * d.OSY + d.ooy[phase];
+                const int ox = gx * d.OSX + d.oox[phase];
+                if (oy < d.OH && ox < d.OW) op = (b * d.OH + oy) * d.OW + ox;
+            }
+        }
+        opix_tab[r] = op;
+    }
+    float biasv[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int nc = n0 + wn * 64 + j * 16 + fr;
+        biasv[j] = (d.bias != nullptr && nc < d.N) ? d.bias[nc] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] += biasv[j];
+    __syncthreads();                                   // opix_tab visible; main-loop LDS reads are done
+
+    if (d.stats != nullptr) {
+        float* red = reinterpret_cast<float*>(smem);   // [WM][BN][2]
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = wm * 64 + i * 16 + fg * 4 + r;
+                    if (opix_tab[row] >= 0) {
+                        const float v = acc[i][j][r];
+                        a += v;
+                        b += v * v;
+                    }
+                }
+            a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
+            b += __shfl_xor(b, 16); b += __shfl_xor(b, 32);
+            if (fg == 0) {
+                const int c = wn * 64 + j * 16 + fr;
+                red[(wm * BN + c) * 2 + 0] = a;
+                red[(wm * BN + c) * 2 + 1] = b;
+            }
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < d.N) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) { a += red[(w * BN + tid) * 2]; b += red[(w * BN + tid) * 2 + 1]; }
+            const int64_t part = (int64_t)phase * m_tiles_ + bx;
+            d.stats[(part * 2 + 0) * d.N + n0 + tid] = a;
+            d.stats[(part * 2 + 1) * d.N + n0 + tid] = b;
+        }
+        __syncthreads();
+    }
+
+    constexpr int CPITCH = BN * ESZ + 16;              // BM rows x 272 B = 34 | 68 KB <= the 48 | 72 KB of stage buffers
+    static_assert(BM * CPITCH <= 2 * GP_PBUF + GP_NB * GP_BST, "C tile does not fit in LDS");
+    constexpr int SEGS = BN * ESZ / 16;
+    unsigned char* Yb = reinterpret_cast<unsigned char*>(d.Y);
+    const int oc_bytes = d.OC * ESZ;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wm * 64 + i * 16 + fg * 4 + r;
+                const int col = wn * 64 + j * 16 + fr;
+                typename E::type* dst = reinterpret_cast<typename E::type*>(smem + row * CPITCH) + col;
+                *dst = E::from_f32(acc[i][j][r]);
+            }
+    __syncthreads();
+    for (int u = tid; u < BM * SEGS; u += NT) {
+        const int row = u / SEGS, seg = u - row * SEGS;
+        const int op = opix_tab[row];
+        const int cb = n0 * ESZ + seg * 16;
+        if (op >= 0 && cb < oc_bytes) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(smem + row * CPITCH + seg * 16);
+            *reinterpret_cast<u32x4*>(Yb + (int64_t)op * oc_bytes + cb) = v;
+        }
+    }
+}
+
+inline bool use_patch() {                   // read per call: tests flip it inside one process
+    const char* e = getenv("VG_GG_PATCH");
+    return e ? atoi(e) != 0 : true;
+}
+
+// Does the descriptor have one of the two patch forms, and does a bm-row tiling (128 or 256) line up?
+inline bool patch_geometry(const vg_gg_desc* d, int bm, PatchGeo* g) {
+    const bool transposed = d->TH == 2 && d->TW == 2 && d->SY == 1 && d->SX == 1 && (d->DY == 1 || d->DY == -1) &&
+                            (d->DX == 1 || d->DX == -1);
+    const bool direct2 = d->TH == 4 && d->TW == 4 && d->SY == 2 && d->SX == 2 && d->DY == 1 && d->DX == 1 &&
+                         d->nphase == 1;
+    if (!transposed && !direct2) return false;
+    if (d->IC % 32 != 0 || d->Kp != d->TH * d->TW * d->IC) return false;
+    const int GW = d->GW, GH = d->GH;
+    if (GW < 4 || GW > 64 || (GW & (GW - 1)) || (GH & (GH - 1))) return false;
+    const int64_t M = (int64_t)d->B * GH * GW;
+    if (M % bm != 0) return false;
+    int R, IMGS;
+    if (GH * GW >= bm) { IMGS = 1; R = bm / GW; if (R < 1 || GH % R) return false; }
+    else { IMGS = bm / (GH * GW); R = GH; }
+    g->R = R; g->IMGS = IMGS; g->PW = GW + 1; g->PIMG = (R + 1) * (GW + 1); g->NPP = IMGS * g->PIMG;
+    if (g->NPP > (bm == 256 ? 384 : 192)) return false;
+    g->ncy = d->TH / 2; g->ncx = d->TW / 2; g->nct = d->IC / 32;
+    return true;
+}
