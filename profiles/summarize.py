@@ -20,7 +20,7 @@ FAMILIES = {"gather_gemm": "gg_kernel", "wgrad": "wgrad_"}
 
 
 def fam_of(name):
-    if "gg_kernel" in name:
+    if "gg_kernel" in name or "ggp_kernel" in name:      # gather-GEMM and its patch variant (conv_patch.hpp)
         return "gather_gemm"
     if "wgrad_bf16_kernel" in name or "wgrad_kernel" in name:
         return "wgrad"
