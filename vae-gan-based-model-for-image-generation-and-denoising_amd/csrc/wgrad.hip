@@ -300,13 +300,22 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const vg_wg_desc d, int
 }
 
 // ---------------------------------------------------------------------------------------------------
-// LDS-DMA variant of the bf16 kernel (opt-in, VG_WG_DMA=1): same 128x128 tile, MFMA and transposed fragment reads, but the
-// operands go global -> LDS with global_load_lds_dwordx4 into a 3-deep ring of 32-row stages (3 x 16 KB = 48 KB,
-// three workgroups per CU), no staging registers, no ds_write.  One wave instruction writes 4 rows x 256 B; a
+// LDS-DMA variant of the bf16 kernel (the default; VG_WG_DMA=0 selects the register-staged one above): same 128x128
+// tile, MFMA and transposed fragment reads, but the operands go global -> LDS with global_load_lds_dwordx4 into a ring
+// of WD_NBUF stages of WD_SM rows (2 x 32 KB = 64 KB, two workgroups per CU), no staging registers, no ds_write.  One wave instruction writes 4 rows x 256 B; a
 // lane's row is 16j + 4*wave + (lane>>4), so (row & 7) -- the swizzle key -- does not depend on j and every lane
 // fetches ONE fixed swizzled source unit (one fixed filter tap / channel offset) for the whole kernel.  Rows past
 // the split range, channels past the tensor and out-of-image taps fetch from a zero page.
-constexpr int WD_SM = 32, WD_NBUF = 3, WD_STAGE = 2 * WD_SM * WB_PITCH;     // 16 KB per stage (P | Q)
+// Ring shape (measured, S=64 B=128 layer sweep, TFLOP/s incl. the slab reduce; register-staged kernel: G1 365,
+// G2 438, G3 487): 32 rows x 3 slots 350 / 430 / 448, 32 x 4 355 / 410 / 451, 32 x 2 357 / 422 / 451,
+// 64 rows x 2 slots 391 / 480 / 512 -- the barrier count per FLOP is what matters, not the depth of the ring.
+#ifndef VG_WD_SM
+#define VG_WD_SM 64
+#endif
+#ifndef VG_WD_NBUF
+#define VG_WD_NBUF 2
+#endif
+constexpr int WD_SM = VG_WD_SM, WD_NBUF = VG_WD_NBUF, WD_STAGE = 2 * WD_SM * WB_PITCH;     // 16 KB per 32-row stage (P | Q)
 
 #define WG_WAITCNT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 
@@ -378,7 +387,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_dma_kernel(const vg_wg_desc d,
                                              16, 0, 0);
         }
     };
-    constexpr int LDMA = 2 * (WD_SM / 16);                   // DMA instructions per wave per stage (= 4)
+    constexpr int LDMA = 2 * (WD_SM / 16);                   // DMA instructions per wave per stage (4 | 8)
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -388,34 +397,41 @@ __global__ __launch_bounds__(256) void wgrad_bf16_dma_kernel(const vg_wg_desc d,
 
     const int nstage = (m_end - m_begin + WD_SM - 1) / WD_SM;
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+    for (int p = 0; p < WD_NBUF; ++p)
         if (p < nstage) fill_table(p, m_begin + p * WD_SM);
     __syncthreads();
-    if (nstage > 0) issue_stage(0, 0, m_begin);
-    if (nstage > 1) issue_stage(1, 1, m_begin + WD_SM);
-    int rb = 0, wb = 2;
+#pragma unroll
+    for (int p = 0; p < WD_NBUF - 1; ++p)
+        if (p < nstage) issue_stage(p, p, m_begin + p * WD_SM);
+    int rb = 0, wb = WD_NBUF - 1;
     for (int s = 0; s < nstage; ++s) {
-        if (s + 1 < nstage) WG_WAITCNT_VM(4);                // LDMA: stage s+1 may stay in flight
+        // stages s+1 .. s+NBUF-2 may stay in flight
+        const int ahead = min(WD_NBUF - 2, nstage - 1 - s);
+        if (ahead * LDMA >= 8) WG_WAITCNT_VM(8);
+        else if (ahead * LDMA >= 4) WG_WAITCNT_VM(4);
         else WG_WAITCNT_VM(0);
         __builtin_amdgcn_s_barrier();
-        if (s + 2 < nstage) issue_stage(wb, (s + 2) & 3, m_begin + (s + 2) * WD_SM);
-        if (s + 3 < nstage) fill_table((s + 3) & 3, m_begin + (s + 3) * WD_SM);
+        if (s + WD_NBUF - 1 < nstage) issue_stage(wb, (s + WD_NBUF - 1) & 3, m_begin + (s + WD_NBUF - 1) * WD_SM);
+        if (s + WD_NBUF < nstage) fill_table((s + WD_NBUF) & 3, m_begin + (s + WD_NBUF) * WD_SM);
         const unsigned char* sp = smem + rb * WD_STAGE;
         const unsigned char* sq = sp + WD_SM * WB_PITCH;
-        bf16x8 a[4], b[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = tr_frag(sp, 0, wnp * 64 + i * 16, lane);
+        for (int ks = 0; ks < WD_SM / 32; ++ks) {
+            bf16x8 a[4], b[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) b[j] = tr_frag(sq, 0, wkq * 64 + j * 16, lane);
+            for (int i = 0; i < 4; ++i) a[i] = tr_frag(sp, ks * 32, wnp * 64 + i * 16, lane);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) b[j] = tr_frag(sq, ks * 32, wkq * 64 + j * 16, lane);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-        rb = rb == 2 ? 0 : rb + 1;
-        wb = wb == 2 ? 0 : wb + 1;
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        rb = rb == WD_NBUF - 1 ? 0 : rb + 1;
+        wb = wb == WD_NBUF - 1 ? 0 : wb + 1;
     }
-    static_assert(LDMA == 4, "vmcnt literal above assumes 4 DMA instructions per stage");
+    static_assert(WD_NBUF >= 2 && WD_NBUF <= 4 && (LDMA == 4 || LDMA == 8), "vmcnt literals above");
     float* slab = d.ws + (int64_t)blockIdx.z * NPpad * (int64_t)(gridDim.x * WB_T);
     const int ldk = gridDim.x * WB_T;
     const int fi = lane & 15, fk = lane >> 4;
@@ -514,10 +530,9 @@ inline int wg_target() {
 inline bool wg_use_dma(const vg_wg_desc* d) {
     static int v = -1;
     if (v < 0) {
-        // opt-in: measured 3 % SLOWER than the register-staged kernel on the S=64 B=128 step (3.81 vs 3.72 ms):
-        // 32-row stages give only 16 MFMAs per barrier, and slab write + reduce are ~25 % of wgrad time either way
+        // default on with 64-row stages (+5..10 % on the generator layers); VG_WG_DMA=0 -> register-staged kernel
         const char* e = getenv("VG_WG_DMA");
-        v = e ? atoi(e) : 0;
+        v = e ? atoi(e) : 1;
     }
     return v != 0 && d->zeros != nullptr;
 }
@@ -543,7 +558,7 @@ inline int make_plan(const vg_wg_desc* d, int dtype, Plan* p) {
     int64_t stages = (M + srows - 1) / srows;
     int nsplit = (int)((wg_target() + tiles - 1) / tiles);    // ~2 workgroups per CU
     // at least 8 (f32) / 4 (bf16) stages of work per workgroup, at most 1024 splits
-    const int min_stages = dtype == VG_F32 ? 8 : (wg_use_dma(d) ? 8 : 4);
+    const int min_stages = dtype == VG_F32 ? 8 : 4;
     if (nsplit > stages / min_stages) nsplit = (int)(stages / min_stages);
     if (nsplit < 1) nsplit = 1;
     if (nsplit > 1024) nsplit = 1024;
