@@ -45,11 +45,21 @@ __device__ __forceinline__ void wait_vmcnt_le(int n) {
     }
 }
 
-// LDS-DMA ring shape (measured, S=64 B=128 layer sweep): the 128x128 tile wants ONE 64-byte chunk per stage
-// (3 x 16 KB ring = 48 KB -> 3 workgroups per CU: G2 445 -> 690, G3 424 -> 622 TFLOP/s), the smaller tiles two.
-#ifndef VG_DMA_NBUF
-#define VG_DMA_NBUF 3
+// LDS-DMA ring shape (measured, S=64 B=128 layer sweeps).  First sweep (one chunk per stage, 3-6 slots) favoured
+// 1 chunk x 3 slots for the 128x128 tile over 2 x 3 (96 KB, one workgroup per CU).  What that sweep missed: TWO
+// chunks per stage in only TWO slots -- half the barriers per FLOP, 64 KB (128x128) / 48 KB (128x64) of LDS, i.e.
+// still 2-3 workgroups per CU: G1 fprop 589 -> 661, G2 703 -> 761 / 595 -> 672, G4 fprop 380 -> 454 TFLOP/s.
+// Only the 64x64 tile (few rows per weight byte, many workgroups) keeps the 3-slot ring (282 vs 239 on D3).
+// VG_DMA_KCH / VG_DMA_NBUF override both for sweeps.
+template <int BM, int BN>
+struct DmaRing {
+#if defined(VG_DMA_KCH) && defined(VG_DMA_NBUF)
+    static constexpr int KCH = VG_DMA_KCH, NBUF = VG_DMA_NBUF;
+#else
+    static constexpr int KCH = 2;
+    static constexpr int NBUF = (BM * BN >= 128 * 64) ? 2 : 3;
 #endif
+};
 
 template <int DT, int BM, int BN, int WM, int WN, bool SPLITK, bool DMA>
 __global__ __launch_bounds__(256) void gg_kernel(const vg_gg_desc d, const int ksplit_arg, const int stages_per_split) {
@@ -61,14 +71,10 @@ __global__ __launch_bounds__(256) void gg_kernel(const vg_gg_desc d, const int k
     constexpr int AP = BM / 64;                    // A row passes per chunk
     constexpr int BP = (BN + 63) / 64;             // B row passes per chunk
     // 64-byte K chunks per barrier (bf16 MFMAs are 16x shorter than f32 ones)
-#ifdef VG_DMA_KCH
-    constexpr int KCH = DMA ? VG_DMA_KCH : ((DT == VG_BF16) ? 2 : 1);
-#else
-    constexpr int KCH = DMA ? ((BM * BN >= 128 * 128) ? 1 : 2) : ((DT == VG_BF16) ? 2 : 1);
-#endif
+    constexpr int KCH = DMA ? DmaRing<BM, BN>::KCH : ((DT == VG_BF16) ? 2 : 1);
     constexpr int CHB = (BM + BN) * 64;            // bytes of one chunk image
     constexpr int STAGE = CHB * KCH;               // bytes per LDS buffer
-    constexpr int NBUF = DMA ? VG_DMA_NBUF : 2;    // DMA path: LDS ring, NBUF-1 stages in flight
+    constexpr int NBUF = DMA ? DmaRing<BM, BN>::NBUF : 2;    // DMA path: LDS ring, NBUF-1 stages in flight
     static_assert(WM * WN == 4, "4 waves");
     static_assert(BM % 64 == 0, "BM multiple of 64");
     static_assert(!DMA || BN % 64 == 0, "DMA path needs whole 16-row wave slices of the B tile");

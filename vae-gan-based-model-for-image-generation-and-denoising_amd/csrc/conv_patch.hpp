@@ -24,7 +24,13 @@ struct PatchGeo {
     int ncy, ncx, nct;              // parity classes per dimension, 32-channel chunks per (class, tap)
 };
 
-constexpr int GP_BN = 128, GP_BST = GP_BN * 64, GP_NB = 3;
+// Taps per barrier stage / weight-ring slots: 1 tap x 3 slots (48.5 KB, 3 workgroups per CU) or 2 taps x 2 slots
+// (56.5 KB, 2 workgroups per CU, half the barriers per FLOP -- the shape that won for gg_kernel and wgrad).
+#ifndef VG_GP_TPS
+#define VG_GP_TPS 2
+#endif
+constexpr int GP_BN = 128, GP_BST = GP_BN * 64, GP_TPS = VG_GP_TPS, GP_NB = GP_TPS == 2 ? 2 : 3;
+constexpr int GP_BSTAGE = GP_TPS * GP_BST;
 
 __device__ __forceinline__ void gp_wait(int n) {
     if (n >= 3) VG_WAITCNT_VM(3);
@@ -43,12 +49,14 @@ template <int WM>
 __global__ __launch_bounds__(128 * WM, WM == 4 ? 4 : 1) void ggp_kernel(const vg_gg_desc d, const PatchGeo g) {
     constexpr int BM = 64 * WM, BN = GP_BN, WN = 2, TM = 4, TN = 4, NT = 128 * WM;
     constexpr int GP_PBUF = 3 * NT * 16;            // 3 DMA rounds of NT lanes x 16 B
+    constexpr int TPS = WM == 4 ? 1 : GP_TPS;      // the 8-wave variant keeps 1 tap x 3 slots (LDS)
+    constexpr int NB = TPS == 2 ? 2 : 3, BSTAGE = TPS * GP_BST;
     constexpr int BJ = 512 / NT;                    // weight-tile DMA instructions per wave and stage (2 / 1)
     // [patch buffers 2 x 12|24 KB][weight ring 3 x 8 KB][output-pixel table]
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * GP_PBUF + GP_NB * GP_BST + BM * 4];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * GP_PBUF + NB * BSTAGE + BM * 4];
     unsigned char* const pbuf = smem;
     unsigned char* const bring = smem + 2 * GP_PBUF;
-    int* const opix_tab = reinterpret_cast<int*>(smem + 2 * GP_PBUF + GP_NB * GP_BST);
+    int* const opix_tab = reinterpret_cast<int*>(smem + 2 * GP_PBUF + NB * BSTAGE);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -130,18 +138,21 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 4 : 1) void ggp_kernel(const vg
         if (++pj_c == g.nct) { pj_c = 0; ++pj_cl; if (pj_cl < ncls) patch_sources(pj_cl); }
     };
     int bs_cl = 0, bs_c = 0, bs_k = 0;                          // (class, chunk, tap-in-class) of the NEXT weight stage
-    auto issue_b = [&](int buf) {
-        const int py = bs_cl / g.ncx, px = bs_cl - py * g.ncx;
-        const int t = ((bs_k >> 1) * g.ncy + py) * d.TW + ((bs_k & 1) * g.ncx + px);
-        const uint32_t koff = ((uint32_t)t * (uint32_t)d.IC + (uint32_t)bs_c * 32u) * 2u;
+    auto issue_b = [&](int buf) {                                // the TPS taps of one stage
 #pragma unroll
-        for (int j = 0; j < BJ; ++j) {
-            const unsigned char* src = b_base[j] + (b_live[j] ? koff : 0u);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(bring + buf * GP_BST + ((NT / 4) * j + 16 * wave_u) * 64),
-                                             16, 0, 0);
+        for (int tp = 0; tp < TPS; ++tp) {
+            const int py = bs_cl / g.ncx, px = bs_cl - py * g.ncx;
+            const int t = ((bs_k >> 1) * g.ncy + py) * d.TW + ((bs_k & 1) * g.ncx + px);
+            const uint32_t koff = ((uint32_t)t * (uint32_t)d.IC + (uint32_t)bs_c * 32u) * 2u;
+#pragma unroll
+            for (int j = 0; j < BJ; ++j) {
+                const unsigned char* src = b_base[j] + (b_live[j] ? koff : 0u);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(bring + buf * BSTAGE + tp * GP_BST + ((NT / 4) * j + 16 * wave_u) * 64),
+                                                 16, 0, 0);
+            }
+            if (++bs_k == 4) { bs_k = 0; if (++bs_c == g.nct) { bs_c = 0; ++bs_cl; } }
         }
-        if (++bs_k == 4) { bs_k = 0; if (++bs_c == g.nct) { bs_c = 0; ++bs_cl; } }
     };
 
     // ---- fragment addressing ----
@@ -175,7 +186,7 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 4 : 1) void ggp_kernel(const vg
             asm volatile("" : "+s"(tapoff));
         }
         const unsigned char* sa = pbuf + pb * GP_PBUF;
-        const unsigned char* sb = bring + bb * GP_BST;
+        const unsigned char* sb = bring + bb * BSTAGE + (k % TPS) * GP_BST;
         u32x4 fa[TM], fb[TN];
         auto ld_a = [&](int i) {
             const int pp = ppbase[i] + tapoff;
@@ -209,12 +220,35 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 4 : 1) void ggp_kernel(const vg
 #endif
     };
 
-    // ---- prologue: patch(0) (3 rounds), weight stages 0 and 1 ----
+    // ---- prologue: patch(0) (3 rounds), then the first weight stage(s) ----
     patch_sources(0);
     issue_patch_round(0, 0);
     issue_patch_round(0, 1);
     issue_patch_round(0, 2);
     patch_advance();
+    if constexpr (TPS == 2) {
+        // ---- two taps per barrier, two weight slots: everything issued during a stage is drained at the next ----
+        issue_b(0);
+        const int S2 = J * 2;
+        int bb = 0, s = 0;
+        for (int j = 0; j < J; ++j) {
+            const int pb = j & 1;
+            const bool more_p = j + 1 < J;
+#pragma unroll
+            for (int h = 0; h < 2; ++h, ++s) {
+                VG_WAITCNT_VM(0);
+                __builtin_amdgcn_s_barrier();
+                if (more_p) {
+                    if (h == 0) { issue_patch_round(pb ^ 1, 0); issue_patch_round(pb ^ 1, 1); }
+                    else { issue_patch_round(pb ^ 1, 2); patch_advance(); }
+                }
+                if (s + 1 < S2) issue_b(bb ^ 1);
+                compute(pb, bb, 2 * h);
+                compute(pb, bb, 2 * h + 1);
+                bb ^= 1;
+            }
+        }
+    } else {
     issue_b(0);
     issue_b(1);
     // ---- main loop over chunks; the 4 tap stages of a chunk are unrolled (static DMA counts per stage) ----
@@ -235,9 +269,10 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 4 : 1) void ggp_kernel(const vg
             }
             if (s + 2 < S) issue_b(wb);
             compute(pb, bb, k);
-            bb = bb == GP_NB - 1 ? 0 : bb + 1;
-            wb = wb == GP_NB - 1 ? 0 : wb + 1;
+            bb = bb == NB - 1 ? 0 : bb + 1;
+            wb = wb == NB - 1 ? 0 : wb + 1;
         }
+    }
     }
 
     // ---------------- epilogue (as gg_kernel<bf16, 128, 128>) ----------------
@@ -313,7 +348,7 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 4 : 1) void ggp_kernel(const vg
     }
 
     constexpr int CPITCH = BN * ESZ + 16;              // BM rows x 272 B = 34 | 68 KB <= the 48 | 72 KB of stage buffers
-    static_assert(BM * CPITCH <= 2 * GP_PBUF + GP_NB * GP_BST, "C tile does not fit in LDS");
+    static_assert(BM * CPITCH <= 2 * GP_PBUF + NB * BSTAGE, "C tile does not fit in LDS");
     constexpr int SEGS = BN * ESZ / 16;
     unsigned char* Yb = reinterpret_cast<unsigned char*>(d.Y);
     const int oc_bytes = d.OC * ESZ;
