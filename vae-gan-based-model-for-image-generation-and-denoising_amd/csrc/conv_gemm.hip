@@ -49,15 +49,25 @@ __device__ __forceinline__ void wait_vmcnt_le(int n) {
 // 1 chunk x 3 slots for the 128x128 tile over 2 x 3 (96 KB, one workgroup per CU).  What that sweep missed: TWO
 // chunks per stage in only TWO slots -- half the barriers per FLOP, 64 KB (128x128) / 48 KB (128x64) of LDS, i.e.
 // still 2-3 workgroups per CU: G1 fprop 589 -> 661, G2 703 -> 761 / 595 -> 672, G4 fprop 380 -> 454 TFLOP/s.
-// Only the 64x64 tile (few rows per weight byte, many workgroups) keeps the 3-slot ring (282 vs 239 on D3).
+// The 64x64 tile (4 MFMAs per chunk and wave) wants FOUR chunks per stage in two slots (64 KB): D3 fprop 283 -> 318,
+// D3 dgrad 427 -> 475, G1 dgrad 500 -> 583 (2 chunks x 3 slots: 282; 2 x 2: 239; 4 x 3: one workgroup per CU, slower).
 // VG_DMA_KCH / VG_DMA_NBUF override both for sweeps.
 template <int BM, int BN>
 struct DmaRing {
 #if defined(VG_DMA_KCH) && defined(VG_DMA_NBUF)
     static constexpr int KCH = VG_DMA_KCH, NBUF = VG_DMA_NBUF;
 #else
-    static constexpr int KCH = 2;
-    static constexpr int NBUF = (BM * BN >= 128 * 64) ? 2 : 3;
+#ifndef VG_RING64_KCH
+#define VG_RING64_KCH 4
+#endif
+#ifndef VG_RING64_NBUF
+#define VG_RING64_NBUF 2
+#endif
+#ifndef VG_RING128x64_KCH
+#define VG_RING128x64_KCH 2
+#endif
+    static constexpr int KCH = (BM * BN >= 128 * 128) ? 2 : (BM * BN >= 128 * 64) ? VG_RING128x64_KCH : VG_RING64_KCH;
+    static constexpr int NBUF = (BM * BN >= 128 * 64) ? 2 : VG_RING64_NBUF;
 #endif
 };
 
