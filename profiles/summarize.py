@@ -22,7 +22,7 @@ FAMILIES = {"gather_gemm": "gg_kernel", "wgrad": "wgrad_"}
 def fam_of(name):
     if "gg_kernel" in name or "ggp_kernel" in name:      # gather-GEMM and its patch variant (conv_patch.hpp)
         return "gather_gemm"
-    if "wgrad_bf16_kernel" in name or "wgrad_kernel" in name:
+    if "wgrad_" in name and "reduce" not in name and "dot_wgrad" not in name:   # wgrad_kernel<..>, wgrad_bf16[_dma]_kernel
         return "wgrad"
     return None
 
