@@ -41,6 +41,7 @@ extern "C" {
 #define VG_ACT_RELU    1   /* nn.ReLU(True)          gan_code.py:23-43            */
 #define VG_ACT_LRELU   2   /* nn.LeakyReLU(slope)    main_vae.py:25, gan_code.py:62-82 */
 
+#define VG_ABI_VERSION 2   /* 2: vg_pack_desc.tile_start, SyncBN / WGAN / data-path entry points */
 int vg_abi_version(void);
 /* Live kernel timing for the roofline report: while enabled, gather-GEMM (family 0) and wgrad (family 1)
  * launches carry a HIP start/stop event pair on their stream (hipExtLaunchKernelGGL); collect() synchronises,

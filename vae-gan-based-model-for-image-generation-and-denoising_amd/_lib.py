@@ -15,7 +15,7 @@ import torch  # noqa: F401  (must be loaded before the HIP library, see module d
 VG_F32, VG_BF16 = 0, 1
 VG_ACT_NONE, VG_ACT_RELU, VG_ACT_LRELU = 0, 1, 2
 VG_MAX_PHASE = 4
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _ERR = {-1: "VG_EINVAL (bad shape/size/flag)", -2: "VG_EALIGN (16-byte contract violated)",
         -3: "VG_ENOSUP (unsupported configuration)"}

@@ -538,5 +538,5 @@ extern "C" int vg_timing_collect(int family, double* total_ms, int* launches) {
     return 0;
 }
 
-extern "C" int vg_abi_version(void) { return 1; }
+extern "C" int vg_abi_version(void) { return VG_ABI_VERSION; }
 extern "C" const char* vg_build_info(void) { return "vaegan_hip gfx950: gather-GEMM f32(16x16x4)/bf16(16x16x32) MFMA"; }
