@@ -156,6 +156,16 @@ int vg_bn_finalize(const float* stats, int nparts, int C, int64_t count,
                    const float* gamma, const float* beta,
                    float* running_mean, float* running_var, float momentum, float eps,
                    float* mean, float* invstd, float* scale, float* shift, void* stream);
+/* The same two reductions for `groups` independent row blocks in ONE launch (a Discriminator iteration's real and
+ * fake batches run as one 2B-row pass): slabs of group g start at stats + g*nparts_per_group*2*C; coeffs is
+ * [groups][4][C] = mean, invstd, scale, shift; coef is [groups][3][C]; running statistics and dgamma/dbeta are
+ * updated group after group, the order in which the reference's separate calls would update them. */
+int vg_bn_finalize_grouped(const float* stats, int nparts_per_group, int groups, int C, int64_t count_per_group,
+                           const float* gamma, const float* beta, float* running_mean, float* running_var,
+                           float momentum, float eps, float* coeffs, void* stream);
+int vg_bn_backward_finalize_grouped(const float* partial, int nparts_per_group, int groups, int C,
+                                    int64_t count_per_group, const float* gamma, const float* coeffs,
+                                    float* dgamma, float* dbeta, int accumulate, float* coef, void* stream);
 /* Synchronised BatchNorm (statistics over the global batch of a one-process-per-GPU job).
  * The reference is single-process (vaegan_code.py:29-35), so "the batch" of nn.BatchNorm2d is the whole batch;
  * these three calls let N ranks reproduce that: vg_slab_sums -> host all-reduce(SUM) of the f64 [2][C] vector

@@ -73,6 +73,8 @@ SIGNATURES = {
     "vg_pack_tile_count": (c_int, [POINTER(PackDesc)]),
     "vg_pack_weights_multi": (c_int, [_P, _I, _L, _I, _P]),
     "vg_bn_finalize": (c_int, [_P, _I, _I, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
+    "vg_bn_finalize_grouped": (c_int, [_P, _I, _I, _I, _L, _P, _P, _P, _P, _F, _F, _P, _P]),
+    "vg_bn_backward_finalize_grouped": (c_int, [_P, _I, _I, _I, _L, _P, _P, _P, _P, _I, _P, _P]),
     "vg_slab_sums": (c_int, [_P, _I, _I, _P, _P]),
     "vg_bn_finalize_sums": (c_int, [_P, _I, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
     "vg_bn_backward_finalize_sums": (c_int, [_P, _P, _I, _L, _P, _P, _P, _P, _I, _P, _P]),

@@ -166,6 +166,63 @@ __global__ __launch_bounds__(FIN_CH * FIN_PL) void bn_finalize_kernel(
     }
 }
 
+// ---- grouped finalize: `groups` independent row blocks (a Discriminator iteration's real and fake batches) in
+// ONE launch; a channel's groups are processed in order by the same thread, so the running statistics are updated
+// real-then-fake exactly as two separate forward calls would (and dgamma/dbeta accumulate in that order).
+__global__ __launch_bounds__(FIN_CH * FIN_PL) void bn_finalize_grouped_kernel(
+    const float* __restrict__ stats, int nparts, int groups, int C, double count, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
+    float* __restrict__ coeffs) {
+    for (int g = 0; g < groups; ++g) {
+        double s1, s2;
+        int c;
+        const bool lead = slab_sums(stats + (int64_t)g * nparts * 2 * C, nparts, C, s1, s2, c);
+        if (lead) {
+            float* co = coeffs + (int64_t)g * 4 * C;
+            const double mu = s1 / count;
+            double var = s2 / count - mu * mu;
+            if (var < 0.0) var = 0.0;
+            const float is = (float)(1.0 / sqrt(var + (double)eps));
+            const float muf = (float)mu;
+            co[c] = muf;
+            co[C + c] = is;
+            const float gm = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+            const float sc = gm * is;
+            co[2 * C + c] = sc;
+            co[3 * C + c] = bt - muf * sc;
+            if (rmean) {
+                const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
+                rmean[c] = (1.f - momentum) * rmean[c] + momentum * muf;
+                rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+            }
+        }
+        __syncthreads();                                    // slab_sums' LDS scratch is reused by the next group
+    }
+}
+
+__global__ __launch_bounds__(FIN_CH * FIN_PL) void bn_bwd_finalize_grouped_kernel(
+    const float* __restrict__ partial, int nparts, int groups, int C, double count, const float* __restrict__ gamma,
+    const float* __restrict__ coeffs, float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
+    float* __restrict__ coef) {
+    for (int g = 0; g < groups; ++g) {
+        double s1, s2;
+        int c;
+        const bool lead = slab_sums(partial + (int64_t)g * nparts * 2 * C, nparts, C, s1, s2, c);
+        if (lead) {
+            const float fs1 = (float)s1, fs2 = (float)s2;
+            const bool acc = accumulate || g > 0;
+            if (dgamma) dgamma[c] = acc ? dgamma[c] + fs2 : fs2;
+            if (dbeta) dbeta[c] = acc ? dbeta[c] + fs1 : fs1;
+            const float a = (gamma ? gamma[c] : 1.f) * coeffs[(int64_t)g * 4 * C + C + c];      // gamma * invstd
+            float* cf = coef + (int64_t)g * 3 * C;
+            cf[c] = a;
+            cf[C + c] = (float)((double)a * s2 / count);
+            cf[2 * C + c] = (float)((double)a * s1 / count);
+        }
+        __syncthreads();
+    }
+}
+
 // ---- synchronised BatchNorm (one process per GPU, statistics over the GLOBAL batch) --------------------------
 // The host all-reduces the f64 [2][C] sums between these kernels (vaegan_amd ddp.py); arithmetic after the sums
 // is the same as bn_finalize_kernel / bn_bwd_finalize_kernel.
@@ -368,6 +425,30 @@ extern "C" int vg_bn_finalize(const float* stats, int nparts, int C, int64_t cou
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_PL), 0, vg_stream(stream), stats, nparts, C,
                        (double)count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale,
                        shift);
+    return VG_LAUNCH_RC();
+}
+
+extern "C" int vg_bn_finalize_grouped(const float* stats, int nparts_per_group, int groups, int C,
+                                      int64_t count_per_group, const float* gamma, const float* beta,
+                                      float* running_mean, float* running_var, float momentum, float eps,
+                                      float* coeffs, void* stream) {
+    VG_CHECK_ARG(stats && coeffs && nparts_per_group > 0 && groups > 0 && C > 0 && count_per_group > 0, VG_EINVAL);
+    VG_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), VG_EINVAL);
+    hipLaunchKernelGGL(bn_finalize_grouped_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_PL), 0,
+                       vg_stream(stream), stats, nparts_per_group, groups, C, (double)count_per_group, gamma, beta,
+                       running_mean, running_var, momentum, eps, coeffs);
+    return VG_LAUNCH_RC();
+}
+
+extern "C" int vg_bn_backward_finalize_grouped(const float* partial, int nparts_per_group, int groups, int C,
+                                               int64_t count_per_group, const float* gamma, const float* coeffs,
+                                               float* dgamma, float* dbeta, int accumulate, float* coef,
+                                               void* stream) {
+    VG_CHECK_ARG(partial && coeffs && coef && nparts_per_group > 0 && groups > 0 && C > 0 && count_per_group > 0,
+                 VG_EINVAL);
+    hipLaunchKernelGGL(bn_bwd_finalize_grouped_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_PL), 0,
+                       vg_stream(stream), partial, nparts_per_group, groups, C, (double)count_per_group, gamma, coeffs,
+                       dgamma, dbeta, accumulate, coef);
     return VG_LAUNCH_RC();
 }
 

@@ -237,12 +237,9 @@ def bn_finalize(stats, nparts, C, count, gamma, beta, running_mean, running_var,
                                                  co[g, 2].data_ptr(), co[g, 3].data_ptr(), L.stream_ptr()),
                     "vg_bn_finalize_sums")
         return co
-    for g in range(groups):
-        sp = stats.data_ptr() + g * npg * 2 * C * 4
-        L.check(L.load().vg_bn_finalize(sp, npg, C, count // groups, L.ptr(gamma), L.ptr(beta),
-                                        L.ptr(running_mean), L.ptr(running_var), momentum, eps,
-                                        co[g, 0].data_ptr(), co[g, 1].data_ptr(), co[g, 2].data_ptr(),
-                                        co[g, 3].data_ptr(), L.stream_ptr()), "vg_bn_finalize")
+    L.check(L.load().vg_bn_finalize_grouped(stats.data_ptr(), npg, groups, C, count // groups, L.ptr(gamma), L.ptr(beta),
+                                            L.ptr(running_mean), L.ptr(running_var), momentum, eps, co.data_ptr(),
+                                            L.stream_ptr()), "vg_bn_finalize_grouped")
     return co
 
 
@@ -301,11 +298,11 @@ def bn_act_backward(x, dy, coeffs, rows, C, count, gamma, act, slope, dgamma, db
                                                      coeffs[g, 1].data_ptr(), L.ptr(dgamma), L.ptr(dbeta),
                                                      1 if (accumulate or g > 0) else 0, coef[g].data_ptr(),
                                                      L.stream_ptr()), "vg_bn_backward_finalize_sums")
-    for g in range(groups if sync is None else 0):
-        pp = partial.data_ptr() + g * n.value * 2 * C * 4
-        L.check(lib.vg_bn_backward_finalize(pp, n.value, C, count // groups, L.ptr(gamma), coeffs[g, 1].data_ptr(),
-                                            L.ptr(dgamma), L.ptr(dbeta), 1 if (accumulate or g > 0) else 0,
-                                            coef[g].data_ptr(), L.stream_ptr()), "vg_bn_backward_finalize")
+    if sync is None:
+        L.check(lib.vg_bn_backward_finalize_grouped(partial.data_ptr(), n.value, groups, C, count // groups, L.ptr(gamma),
+                                                    coeffs.data_ptr(), L.ptr(dgamma), L.ptr(dbeta),
+                                                    1 if accumulate else 0, coef.data_ptr(), L.stream_ptr()),
+                "vg_bn_backward_finalize_grouped")
     dx = torch.empty_like(x)
     L.check(lib.vg_bn_act_backward_apply(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), coeffs[0, 2].data_ptr(),
                                          coeffs[0, 3].data_ptr(), coeffs[0, 0].data_ptr(), coeffs[0, 1].data_ptr(),
