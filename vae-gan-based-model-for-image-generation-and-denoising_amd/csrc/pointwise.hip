@@ -13,16 +13,22 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t b = i / HW;
         const int64_t hw = i - b * HW;
-        for (int c = 0; c < CP; ++c) {
-            float v = 0.f;
-            if (c < C) {
-                const int64_t src = (b * C + c) * HW + hw;
-                v = x[src];
-                if (eps) v = v + sigma * eps[src];
-                v = fminf(fmaxf(v, lo), hi);
-                if (y_nchw) y_nchw[src] = v;
+        for (int c0 = 0; c0 < CP; c0 += 4) {          // CP % 4 == 0: one 8- / 16-byte store per 4 channels
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = c0 + k;
+                v[k] = 0.f;
+                if (c < C) {
+                    const int64_t src = (b * C + c) * HW + hw;
+                    float t = x[src];
+                    if (eps) t = t + sigma * eps[src];
+                    t = fminf(fmaxf(t, lo), hi);
+                    if (y_nchw) y_nchw[src] = t;
+                    v[k] = t;
+                }
             }
-            store1<DT>(y, i * CP + c, v);
+            store4<DT>(y, i * CP + c0, float4{v[0], v[1], v[2], v[3]});
         }
     }
 }
@@ -54,10 +60,14 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const void* __restric
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t b = i / HW;
         const int64_t hw = i - b * HW;
-        for (int c = 0; c < C; ++c) {
-            float v = load1<DT>(x, i * CP + c);
-            if (apply_tanh) v = tanhf(v);
-            y[(b * C + c) * HW + hw] = v;
+        for (int c0 = 0; c0 < C; c0 += 4) {           // CP % 4 == 0: one 8- / 16-byte load per 4 channels
+            const float4 q = load4<DT>(x, i * CP + c0);
+            const float v[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = c0 + k;
+                if (c < C) y[(b * C + c) * HW + hw] = apply_tanh ? tanhf(v[k]) : v[k];
+            }
         }
     }
 }
@@ -69,14 +79,19 @@ __global__ __launch_bounds__(256) void nchw_grad_to_nhwc_kernel(const float* __r
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t b = i / HW;
         const int64_t hw = i - b * HW;
-        for (int c = 0; c < CP; ++c) {
-            float v = 0.f;
-            if (c < C) {
-                const int64_t src = (b * C + c) * HW + hw;
-                v = dy[src];
-                if (t) { const float tv = t[src]; v = v * (1.f - tv * tv); }
+        for (int c0 = 0; c0 < CP; c0 += 4) {
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = c0 + k;
+                v[k] = 0.f;
+                if (c < C) {
+                    const int64_t src = (b * C + c) * HW + hw;
+                    v[k] = dy[src];
+                    if (t) { const float tv = t[src]; v[k] = v[k] * (1.f - tv * tv); }
+                }
             }
-            store1<DT>(dx, i * CP + c, v);
+            store4<DT>(dx, i * CP + c0, float4{v[0], v[1], v[2], v[3]});
         }
     }
 }
@@ -385,7 +400,7 @@ inline int blocks_for(int64_t n, int cap = 4096) {
 extern "C" int vg_nchw_to_nhwc(const float* x, const float* eps, float sigma, void* y, int B, int C, int H, int W,
                                int CP, int dtype, void* stream) {
     CHECK_DT();
-    VG_CHECK_ARG(x && y && B > 0 && C > 0 && H > 0 && W > 0 && CP >= C, VG_EINVAL);
+    VG_CHECK_ARG(x && y && B > 0 && C > 0 && H > 0 && W > 0 && CP >= C && CP % 4 == 0, VG_EINVAL);
     const int64_t npix = (int64_t)B * H * W;
     DISPATCH_DT(nchw_to_nhwc_kernel, dim3(blocks_for(npix)), dim3(256), vg_stream(stream), x, eps, sigma, y, npix, C,
                 H * W, CP, -3.0e38f, 3.0e38f, (float*)nullptr);
@@ -404,7 +419,7 @@ extern "C" int vg_gather_normalize_u8(const uint8_t* images, int64_t N, const in
 extern "C" int vg_noisy_clamp_to_nhwc(const float* x, const float* eps, float sigma, float lo, float hi, void* y,
                                       float* y_nchw, int B, int C, int H, int W, int CP, int dtype, void* stream) {
     CHECK_DT();
-    VG_CHECK_ARG(x && eps && y && B > 0 && C > 0 && H > 0 && W > 0 && CP >= C && lo <= hi, VG_EINVAL);
+    VG_CHECK_ARG(x && eps && y && B > 0 && C > 0 && H > 0 && W > 0 && CP >= C && CP % 4 == 0 && lo <= hi, VG_EINVAL);
     const int64_t npix = (int64_t)B * H * W;
     DISPATCH_DT(nchw_to_nhwc_kernel, dim3(blocks_for(npix)), dim3(256), vg_stream(stream), x, eps, sigma, y, npix, C,
                 H * W, CP, lo, hi, y_nchw);
@@ -414,7 +429,7 @@ extern "C" int vg_noisy_clamp_to_nhwc(const float* x, const float* eps, float si
 extern "C" int vg_nhwc_to_nchw(const void* x, float* y, int B, int C, int H, int W, int CP, int apply_tanh, int dtype,
                                void* stream) {
     CHECK_DT();
-    VG_CHECK_ARG(x && y && B > 0 && C > 0 && H > 0 && W > 0 && CP >= C, VG_EINVAL);
+    VG_CHECK_ARG(x && y && B > 0 && C > 0 && H > 0 && W > 0 && CP >= C && CP % 4 == 0, VG_EINVAL);
     const int64_t npix = (int64_t)B * H * W;
     DISPATCH_DT(nhwc_to_nchw_kernel, dim3(blocks_for(npix)), dim3(256), vg_stream(stream), x, y, npix, C, H * W, CP,
                 apply_tanh);
@@ -424,7 +439,7 @@ extern "C" int vg_nhwc_to_nchw(const void* x, float* y, int B, int C, int H, int
 extern "C" int vg_nchw_grad_to_nhwc(const float* dy, const float* tanh_out, void* dx, int B, int C, int H, int W,
                                     int CP, int dtype, void* stream) {
     CHECK_DT();
-    VG_CHECK_ARG(dy && dx && B > 0 && C > 0 && H > 0 && W > 0 && CP >= C, VG_EINVAL);
+    VG_CHECK_ARG(dy && dx && B > 0 && C > 0 && H > 0 && W > 0 && CP >= C && CP % 4 == 0, VG_EINVAL);
     const int64_t npix = (int64_t)B * H * W;
     DISPATCH_DT(nchw_grad_to_nhwc_kernel, dim3(blocks_for(npix)), dim3(256), vg_stream(stream), dy, tanh_out, dx, npix,
                 C, H * W, CP);
