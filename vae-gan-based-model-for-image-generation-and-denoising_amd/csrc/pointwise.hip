@@ -122,7 +122,20 @@ __global__ __launch_bounds__(1024) void kl_kernel(const void* __restrict__ mulv,
     __shared__ double red[16];
     double s = 0.0;
     const int total = B * L;
-    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+    int i = threadIdx.x;
+    for (; i + 3 * (int)blockDim.x < total; i += 4 * blockDim.x) {        // four element pairs in flight per thread
+        float mu[4], lv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = i + u * blockDim.x;
+            const int b = e / L, j = e - b * L;
+            mu[u] = load1<DT>(mulv, (int64_t)b * MP + j);
+            lv[u] = lvc[e];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s += (double)(1.f + lv[u] - mu[u] * mu[u] - expf(lv[u]));
+    }
+    for (; i < total; i += blockDim.x) {
         const int b = i / L, j = i - b * L;
         const float mu = load1<DT>(mulv, (int64_t)b * MP + j);
         const float lv = lvc[i];
