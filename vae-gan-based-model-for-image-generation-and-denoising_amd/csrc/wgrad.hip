@@ -477,18 +477,44 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const vg_wg_desc d, i
 #pragma unroll
             for (int v = 0; v < VC; ++v) s[j][v] = 0.f;
         if (ok) {
-            for (int k = sp; k < nsplit; k += SPL) {
+            // U slab rows (U * TT loads) in flight per thread: one row at a time made the walk over up to 32 rows a
+            // chain of dependent L2 latencies (11 us per launch, 23 launches per step)
+            constexpr int U = (TT <= 4) ? 4 : 1;
+            auto row = [&](int k, float (&acc)[TT][VC]) {
 #pragma unroll
-                for (int j = 0; j < TT; ++j)
+                for (int j = 0; j < TT; ++j) {
+#pragma unroll
+                    for (int v = 0; v < VC; ++v) acc[j][v] = 0.f;
                     if (t0 + j < T) {
                         const float* q = src + k * slab_stride + (int64_t)(t0 + j) * d.QC;
                         if (VC == 4) {
                             const float4 x = *reinterpret_cast<const float4*>(q);
-                            s[j][0] += x.x; s[j][1 % VC] += x.y; s[j][2 % VC] += x.z; s[j][3 % VC] += x.w;
+                            acc[j][0] = x.x; acc[j][1 % VC] = x.y; acc[j][2 % VC] = x.z; acc[j][3 % VC] = x.w;
                         } else {
-                            s[j][0] += q[0];
+                            acc[j][0] = q[0];
                         }
                     }
+                }
+            };
+            int k = sp;
+            for (; k + (U - 1) * SPL < nsplit; k += U * SPL) {
+                float t[U][TT][VC];
+#pragma unroll
+                for (int u = 0; u < U; ++u) row(k + u * SPL, t[u]);
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int j = 0; j < TT; ++j)
+#pragma unroll
+                        for (int v = 0; v < VC; ++v) s[j][v] += t[u][j][v];
+            }
+            for (; k < nsplit; k += SPL) {
+                float t[TT][VC];
+                row(k, t);
+#pragma unroll
+                for (int j = 0; j < TT; ++j)
+#pragma unroll
+                    for (int v = 0; v < VC; ++v) s[j][v] += t[j][v];
             }
         }
         // all partials -> LDS once; then every thread adds the SPL partials of a few outputs in fixed order,
