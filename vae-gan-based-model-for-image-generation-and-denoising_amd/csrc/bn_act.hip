@@ -62,13 +62,11 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const void* __restrict_
             mu = *reinterpret_cast<const float4*>(mean + go + c4);
             is = *reinterpret_cast<const float4*>(invstd + go + c4);
         }
-        for (int64_t r = r0 + tr; r < r1; r += rpp) {
-            const float4 v = load4<DT>(x, r * C + c4);
+        auto accum = [&](const float4& v, const float4& g) {
             if (MODE == 0) {
                 s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
                 s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
             } else {
-                const float4 g = load4<DT>(dy, r * C + c4);
                 const float dz0 = act_bwd(sc.x * v.x + sh.x, g.x, act, slope);
                 const float dz1 = act_bwd(sc.y * v.y + sh.y, g.y, act, slope);
                 const float dz2 = act_bwd(sc.z * v.z + sh.z, g.z, act, slope);
@@ -77,6 +75,23 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const void* __restrict_
                 s2.x += dz0 * ((v.x - mu.x) * is.x); s2.y += dz1 * ((v.y - mu.y) * is.y);
                 s2.z += dz2 * ((v.z - mu.z) * is.z); s2.w += dz3 * ((v.w - mu.w) * is.w);
             }
+        };
+        // four rows (eight loads) in flight per thread; summation order unchanged
+        int64_t r = r0 + tr;
+        for (; r + 3 * rpp < r1; r += 4 * rpp) {
+            float4 v[4], g[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                v[u] = load4<DT>(x, (r + (int64_t)u * rpp) * C + c4);
+                g[u] = (MODE == 1) ? load4<DT>(dy, (r + (int64_t)u * rpp) * C + c4) : float4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) accum(v[u], g[u]);
+        }
+        for (; r < r1; r += rpp) {
+            const float4 v = load4<DT>(x, r * C + c4);
+            const float4 g = (MODE == 1) ? load4<DT>(dy, r * C + c4) : float4{0.f, 0.f, 0.f, 0.f};
+            accum(v, g);
         }
     }
     red[0][tid] = s1;
@@ -293,9 +308,8 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const void* __restrict_
                                                          const float* __restrict__ shift, int64_t nvec, int cols,
                                                          int act, float slope, int64_t nvec_per_group,
                                                          int64_t gstride) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    auto one = [&](int64_t i, float4 v) {
         const int c4 = (int)(i % cols) * 4;
-        float4 v = load4<DT>(x, i * 4);
         if (scale) {
             const int64_t go = (i / nvec_per_group) * gstride;
             const float4 sc = *reinterpret_cast<const float4*>(scale + go + c4);
@@ -305,7 +319,18 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const void* __restrict_
         v.x = act_fwd(v.x, act, slope); v.y = act_fwd(v.y, act, slope);
         v.z = act_fwd(v.z, act, slope); v.w = act_fwd(v.w, act, slope);
         store4<DT>(y, i * 4, v);
+    };
+    // four vectors in flight per thread (the grid is capped: big tensors give each thread several iterations)
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < nvec; i += 4 * stride) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = load4<DT>(x, (i + u * stride) * 4);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) one(i + u * stride, v[u]);
     }
+    for (; i < nvec; i += stride) one(i, load4<DT>(x, i * 4));
 }
 
 __global__ __launch_bounds__(FIN_CH * FIN_PL) void bn_bwd_finalize_kernel(
@@ -334,10 +359,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const void* __res
                                                                const float* __restrict__ coef, int64_t nvec, int cols,
                                                                int C, int act, float slope, int64_t nvec_per_group,
                                                                int64_t gstride, int64_t cstride) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    auto one = [&](int64_t i, const float4& v, const float4& g) {
         const int c4 = (int)(i % cols) * 4;
-        const float4 v = load4<DT>(x, i * 4);
-        const float4 g = load4<DT>(dy, i * 4);
         const int64_t grp = i / nvec_per_group;
         const int64_t go = grp * gstride;
         const float* cf = coef + grp * cstride;
@@ -354,20 +377,38 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const void* __res
         o.z = ca.z * act_bwd(sc.z * v.z + sh.z, g.z, act, slope) - cbv.z * ((v.z - mu.z) * is.z) - cc.z;
         o.w = ca.w * act_bwd(sc.w * v.w + sh.w, g.w, act, slope) - cbv.w * ((v.w - mu.w) * is.w) - cc.w;
         store4<DT>(dx, i * 4, o);
+    };
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < nvec; i += 4 * stride) {          // eight loads in flight per thread
+        float4 v[4], g[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { v[u] = load4<DT>(x, (i + u * stride) * 4); g[u] = load4<DT>(dy, (i + u * stride) * 4); }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) one(i + u * stride, v[u], g[u]);
     }
+    for (; i < nvec; i += stride) one(i, load4<DT>(x, i * 4), load4<DT>(dy, i * 4));
 }
 
 template <int DT>
 __global__ __launch_bounds__(256) void act_bwd_kernel(const void* __restrict__ x, const void* __restrict__ dy,
                                                       void* __restrict__ dx, int64_t nvec, int act, float slope) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
-        const float4 v = load4<DT>(x, i * 4);
-        const float4 g = load4<DT>(dy, i * 4);
+    auto one = [&](int64_t i, const float4& v, const float4& g) {
         float4 o;
         o.x = act_bwd(v.x, g.x, act, slope); o.y = act_bwd(v.y, g.y, act, slope);
         o.z = act_bwd(v.z, g.z, act, slope); o.w = act_bwd(v.w, g.w, act, slope);
         store4<DT>(dx, i * 4, o);
+    };
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < nvec; i += 4 * stride) {
+        float4 v[4], g[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { v[u] = load4<DT>(x, (i + u * stride) * 4); g[u] = load4<DT>(dy, (i + u * stride) * 4); }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) one(i + u * stride, v[u], g[u]);
     }
+    for (; i < nvec; i += stride) one(i, load4<DT>(x, i * 4), load4<DT>(dy, i * 4));
 }
 
 __global__ __launch_bounds__(FIN_CH * FIN_PL) void bias_finalize_kernel(const float* __restrict__ partial, int nparts,
