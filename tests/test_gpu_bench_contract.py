@@ -1,0 +1,42 @@
+"""GPU: bench.py's output contract (one JSON line on stdout with the driver's keys, roofline and cpu_baseline objects)
+and __graft_entry__.smoke()."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_prints_one_json_line_with_the_contract_keys():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2", "--batch", "32"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "images/sec" and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 2
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "bf16" and d["data"] == "synthetic" and "workload" in d["config"]
+    assert abs(d["value"] - 32 / (d["ms_per_step"] / 1e3)) / d["value"] < 1e-2
+    ro = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in ro, k
+    assert ro["bound"] == "mfma" and ro["unit"] == "TFLOP/s" and ro["peak"] == 2500.0
+    assert abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-3 and 0 < ro["frac"] < 1
+    cb = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in cb, k
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
+
+
+def test_graft_entry_smoke():
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    g.smoke()
