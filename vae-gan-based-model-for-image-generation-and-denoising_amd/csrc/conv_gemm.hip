@@ -607,6 +607,11 @@ inline int min_wgs() {                      // read per call (a few hundred ns):
 }
 
 // (a 256x128 tile -- wave tile 128x64, 152 VGPRs, one wave per SIMD -- was measured and loses on every layer)
+inline bool patch64() {                     // patch variant for the 128 x 64 tile (VG_GG_PATCH64=0 turns it off)
+    const char* e = getenv("VG_GG_PATCH64");
+    return e ? atoi(e) != 0 : true;
+}
+
 inline int patch256_min() {
     const char* e = getenv("VG_PATCH256_MIN");
     return e ? atoi(e) : 0x7fffffff;        // the 8-wave patch variant is opt-in (measured slower, conv_patch.hpp)
@@ -739,11 +744,12 @@ extern "C" int vg_gather_gemm(const vg_gg_desc* d, int dtype, void* stream) {
     }
     if (dtype == VG_F32) return dispatch<VG_F32>(d, t, vg_stream(stream), sk);
     PatchGeo pg;
-    if ((t.bm == 128 || t.bm == 256) && t.bn == GP_BN && sk.ksplit <= 1 && use_patch() && use_dma() &&
-        d->zeros != nullptr && patch_geometry(d, t.bm, &pg)) {
-        const int m_tiles = (d->B * d->GH * d->GW) / t.bm, n_tiles = (d->N + GP_BN - 1) / GP_BN;
+    if ((t.bm == 128 || t.bm == 256) && (t.bn == GP_BN || (t.bn == 64 && t.bm == 128 && patch64())) && sk.ksplit <= 1 &&
+        use_patch() && use_dma() && d->zeros != nullptr && patch_geometry(d, t.bm, &pg)) {
+        const int m_tiles = (d->B * d->GH * d->GW) / t.bm, n_tiles = (d->N + t.bn - 1) / t.bn;
         dim3 grid(((m_tiles + 7) / 8) * 8 * n_tiles, 1, d->nphase);
         if (t.bm == 256) vg_launch_timed(0, ggp_kernel<4>, grid, dim3(512), 0, vg_stream(stream), *d, pg);
+        else if (t.bn == 64) vg_launch_timed(0, (ggp_kernel<2, 64>), grid, dim3(256), 0, vg_stream(stream), *d, pg);
         else vg_launch_timed(0, ggp_kernel<2>, grid, dim3(256), 0, vg_stream(stream), *d, pg);
         return VG_LAUNCH_RC();
     }

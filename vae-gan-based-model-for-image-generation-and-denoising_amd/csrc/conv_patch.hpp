@@ -45,13 +45,15 @@ __device__ __forceinline__ void gp_wait(int n) {
 //         MI355X (G3 dgrad 542 vs 800, G4 dgrad 553 vs 747 TFLOP/s): the register cap spills (36 dwords) and drops
 //         the hoisted fragment addresses.  Kept selectable (VG_PATCH256_MIN=<min tiles>) as the starting point for a
 //         leaner 8-wave kernel; never chosen by default.
-template <int WM>
+template <int WM, int BN = GP_BN>
 __global__ __launch_bounds__(128 * WM, WM == 4 ? 4 : 1) void ggp_kernel(const vg_gg_desc d, const PatchGeo g) {
-    constexpr int BM = 64 * WM, BN = GP_BN, WN = 2, TM = 4, TN = 4, NT = 128 * WM;
+    // BN = 128: wave tile 64 x 64; BN = 64 (layers with <= 64 output channels): wave tile 64 x 32
+    constexpr int BM = 64 * WM, WN = 2, TM = 4, TN = BN / 32, NT = 128 * WM, BST = BN * 64, WNC = BN / 2;
     constexpr int GP_PBUF = 3 * NT * 16;            // 3 DMA rounds of NT lanes x 16 B
     constexpr int TPS = WM == 4 ? 1 : GP_TPS;      // the 8-wave variant keeps 1 tap x 3 slots (LDS)
-    constexpr int NB = TPS == 2 ? 2 : 3, BSTAGE = TPS * GP_BST;
-    constexpr int BJ = 512 / NT;                    // weight-tile DMA instructions per wave and stage (2 / 1)
+    constexpr int NB = TPS == 2 ? 2 : 3, BSTAGE = TPS * BST;
+    constexpr int BJ = (BN * 4) / NT;               // weight-tile DMA instructions per wave and tap (2 / 1)
+    static_assert(BN == 128 || (BN == 64 && WM == 2), "supported shapes");
     // [patch buffers 2 x 12|24 KB][weight ring 3 x 8 KB][output-pixel table]
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * GP_PBUF + NB * BSTAGE + BM * 4];
     unsigned char* const pbuf = smem;
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 4 : 1) void ggp_kernel(const vg
             for (int j = 0; j < BJ; ++j) {
                 const unsigned char* src = b_base[j] + (b_live[j] ? koff : 0u);
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(bring + buf * BSTAGE + tp * GP_BST + ((NT / 4) * j + 16 * wave_u) * 64),
+                                                 (__attribute__((address_space(3))) void*)(bring + buf * BSTAGE + tp * BST + ((NT / 4) * j + 16 * wave_u) * 64),
                                                  16, 0, 0);
             }
             if (++bs_k == 4) { bs_k = 0; if (++bs_c == g.nct) { bs_c = 0; ++bs_cl; } }
@@ -186,38 +188,51 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 4 : 1) void ggp_kernel(const vg
             asm volatile("" : "+s"(tapoff));
         }
         const unsigned char* sa = pbuf + pb * GP_PBUF;
-        const unsigned char* sb = bring + bb * BSTAGE + (k % TPS) * GP_BST;
+        const unsigned char* sb = bring + bb * BSTAGE + (k % TPS) * BST;
         u32x4 fa[TM], fb[TN];
         auto ld_a = [&](int i) {
             const int pp = ppbase[i] + tapoff;
             fa[i] = *reinterpret_cast<const u32x4*>(sa + pp * 64 + ((fg ^ ((-(pp >> 2)) & 3)) << 4));
         };
         auto ld_b = [&](int j) {
-            const int r = wn * 64 + j * 16 + fr;
+            const int r = wn * WNC + j * 16 + fr;
             fb[j] = *reinterpret_cast<const u32x4*>(sb + r * 64 + ((fg ^ ((-(r >> 2)) & 3)) << 4));
         };
-        ld_a(0); ld_b(0); ld_b(1); ld_a(1); ld_b(2); ld_a(2); ld_b(3); ld_a(3);
 #define GP_MFMA(i, j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]), \
                                                                   __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0)
-        // MFMAs in the order their fragments arrive (fa0 fb0 | fb1 | fa1 | fb2 | fa2 | fb3 | fa3) ...
-        GP_MFMA(0, 0);
-        GP_MFMA(0, 1);
-        GP_MFMA(1, 0); GP_MFMA(1, 1);
-        GP_MFMA(0, 2); GP_MFMA(1, 2);
-        GP_MFMA(2, 0); GP_MFMA(2, 1); GP_MFMA(2, 2);
-        GP_MFMA(0, 3); GP_MFMA(1, 3); GP_MFMA(2, 3);
-        GP_MFMA(3, 0); GP_MFMA(3, 1); GP_MFMA(3, 2); GP_MFMA(3, 3);
-#undef GP_MFMA
+        if constexpr (TN == 4) {
+            ld_a(0); ld_b(0); ld_b(1); ld_a(1); ld_b(2); ld_a(2); ld_b(3); ld_a(3);
+            // MFMAs in the order their fragments arrive (fa0 fb0 | fb1 | fa1 | fb2 | fa2 | fb3 | fa3) ...
+            GP_MFMA(0, 0);
+            GP_MFMA(0, 1);
+            GP_MFMA(1, 0); GP_MFMA(1, 1);
+            GP_MFMA(0, 2); GP_MFMA(1, 2);
+            GP_MFMA(2, 0); GP_MFMA(2, 1); GP_MFMA(2, 2);
+            GP_MFMA(0, 3); GP_MFMA(1, 3); GP_MFMA(2, 3);
+            GP_MFMA(3, 0); GP_MFMA(3, 1); GP_MFMA(3, 2); GP_MFMA(3, 3);
 #ifndef VG_NO_SCHED
-        // ... and a scheduling pipeline that interleaves the ds_read_b128s with them instead of "all reads, wait for
-        // everything, all MFMAs" (0x100 = DS read, 0x008 = MFMA)
-        // two reads stay in flight ahead of the MFMA that needs them (counted lgkmcnt waits, no drain)
-        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 10, 0);
+            // ... and a scheduling pipeline that interleaves the ds_read_b128s with them instead of "all reads, wait
+            // for everything, all MFMAs" (0x100 = DS read, 0x008 = MFMA): two reads stay in flight ahead of the MFMA
+            // that needs them
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 10, 0);
 #endif
+        } else {
+            ld_a(0); ld_b(0); ld_b(1); ld_a(1); ld_a(2); ld_a(3);
+            GP_MFMA(0, 0); GP_MFMA(0, 1);
+            GP_MFMA(1, 0); GP_MFMA(1, 1);
+            GP_MFMA(2, 0); GP_MFMA(2, 1);
+            GP_MFMA(3, 0); GP_MFMA(3, 1);
+#ifndef VG_NO_SCHED
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0); __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+#endif
+        }
+#undef GP_MFMA
     };
 
     // ---- prologue: patch(0) (3 rounds), then the first weight stage(s) ----
@@ -300,7 +315,7 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 4 : 1) void ggp_kernel(const vg
     float biasv[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int nc = n0 + wn * 64 + j * 16 + fr;
+        const int nc = n0 + wn * WNC + j * 16 + fr;
         biasv[j] = (d.bias != nullptr && nc < d.N) ? d.bias[nc] : 0.f;
     }
 #pragma unroll
@@ -330,7 +345,7 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 4 : 1) void ggp_kernel(const vg
             a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
             b += __shfl_xor(b, 16); b += __shfl_xor(b, 32);
             if (fg == 0) {
-                const int c = wn * 64 + j * 16 + fr;
+                const int c = wn * WNC + j * 16 + fr;
                 red[(wm * BN + c) * 2 + 0] = a;
                 red[(wm * BN + c) * 2 + 1] = b;
             }
@@ -359,7 +374,7 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 4 : 1) void ggp_kernel(const vg
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = wm * 64 + i * 16 + fg * 4 + r;
-                const int col = wn * 64 + j * 16 + fr;
+                const int col = wn * WNC + j * 16 + fr;
                 typename E::type* dst = reinterpret_cast<typename E::type*>(smem + row * CPITCH) + col;
                 *dst = E::from_f32(acc[i][j][r]);
             }
