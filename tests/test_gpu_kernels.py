@@ -332,6 +332,8 @@ PATCH_CASES = [  # kind, B, H (input), Cin, Cout      (k4 s2 p1 everywhere; all 
     ("conv_dgrad", 8, 32, 128, 64), ("conv_dgrad", 4, 16, 256, 96),          # transposed form, N = Cin
     ("convT_dgrad", 8, 16, 128, 128), ("convT_dgrad", 4, 8, 160, 64),        # direct stride-2 form, N = Cin
     ("convT", 8, 16, 128, 64), ("conv", 8, 32, 64, 64), ("conv_dgrad", 8, 32, 64, 128), ("convT", 2, 32, 96, 40),  # 128 x 64 tile
+    ("convT", 16, 4, 256, 128), ("conv", 16, 8, 128, 256), ("convT_dgrad", 16, 4, 128, 256),   # 4 x 4 grids: 8 images per tile
+    ("convT", 2, 64, 32, 128), ("conv", 2, 128, 32, 128),                                     # 64-wide grids
 ]
 
 
@@ -375,8 +377,8 @@ def test_patch_gather_gemm_equals_reference_and_gather_path(ops, monkeypatch, ki
         monkeypatch.setenv("VG_PATCH256_MIN", "1" if mode == "patch256" else "2000000000")
         Y, st, nparts = ops.gather_gemm(gg, X, Wp, dtype, want_stats=True)
         M = gg.B * gg.GH * gg.GW
-        narrow = gg.N <= 64                                         # those layers take the 128 x 64 tile (no 256-row variant)
-        assert nparts == gg.nphase * (M // (256 if (mode == "patch256" and not narrow) else 128))
+        # 256-row tiles only where the 8-wave variant applies (N > 64 and a patch of <= 384 pixels), else 128-row tiles
+        assert nparts in ((gg.nphase * (M // 128),) if mode != "patch256" else (gg.nphase * (M // 128), gg.nphase * (M // 256)))
         outs[mode] = (from_nhwc(Y.double().cpu(), nout), st[: nparts * 2 * nout].view(nparts, 2, nout).double().sum(0).cpu())
     close(outs[variant][0], ref, dtype)
     # same products, different summation order (class/chunk/tap instead of tap/chunk): bf16 output rounding apart

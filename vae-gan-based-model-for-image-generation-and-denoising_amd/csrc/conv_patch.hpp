@@ -13,7 +13,7 @@
 //   * one phase of the 4-phase transposed form: TH = TW = 2, SY = SX = 1, DY, DX = +-1 (blockIdx.z = phase);
 //   * the direct stride-2 4x4 convolution: TH = TW = 4, SY = SX = 2, DY = DX = 1, split into its 4 input-parity
 //     classes, each of which IS a 2x2-tap stride-1 form on the parity-subsampled input.
-// Tile = 128 consecutive grid pixels = IMGS images x R whole grid rows (GW a power of two <= 64).
+// Tile = 128 consecutive grid pixels = IMGS images x R whole grid rows (GW a power of two, 4 ... 64).
 //
 // Pipeline per workgroup: chunks j = (class, 32-channel chunk); patch(j) lives in pbuf[j & 1] and is fetched while
 // chunk j-1 is multiplied (3 DMA rounds, one per tap stage); weight tiles ride a 3-deep ring, 2 stages ahead, exactly
@@ -49,7 +49,8 @@ template <int WM, int BN = GP_BN>
 __global__ __launch_bounds__(128 * WM, WM == 4 ? 4 : 1) void ggp_kernel(const vg_gg_desc d, const PatchGeo g) {
     // BN = 128: wave tile 64 x 64; BN = 64 (layers with <= 64 output channels): wave tile 64 x 32
     constexpr int BM = 64 * WM, WN = 2, TM = 4, TN = BN / 32, NT = 128 * WM, BST = BN * 64, WNC = BN / 2;
-    constexpr int GP_PBUF = 3 * NT * 16;            // 3 DMA rounds of NT lanes x 16 B
+    constexpr int NR = (WM == 4 || GP_TPS != 2) ? 3 : 4;   // patch DMA rounds: 192 (3) or 256 (4) pixels per 128 rows
+    constexpr int GP_PBUF = NR * NT * 16;           // NR rounds of NT lanes x 16 B
     constexpr int TPS = WM == 4 ? 1 : GP_TPS;      // the 8-wave variant keeps 1 tap x 3 slots (LDS)
     constexpr int NB = TPS == 2 ? 2 : 3, BSTAGE = TPS * BST;
     constexpr int BJ = (BN * 4) / NT;               // weight-tile DMA instructions per wave and tap (2 / 1)
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 4 : 1) void ggp_kernel(const vg
     }
     // ---- patch DMA lanes: LDS slot sidx = NT*r + tid -> pixel pp = sidx >> 2, stored unit sidx & 3.  The lane's
     // pixel coordinates are recomputed at every class change (<= 4 times per kernel) rather than kept in registers.
-    const unsigned char* a_cur[3];
+    const unsigned char* a_cur[NR];
     uint32_t a_live = 0;                                         // bit r: round r reads real data (else the zero page)
     auto patch_sources = [&](int cl) {
         const int py = cl / g.ncx, px = cl - py * g.ncx;
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 4 : 1) void ggp_kernel(const vg
         const int cx = d.x0[phase] + d.DX * px - (d.DX < 0 ? d.SX : 0);
         a_live = 0;
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
+        for (int r = 0; r < NR; ++r) {
             const int sidx = NT * r + tid;
             const int pp = sidx >> 2;
             const int q = (sidx & 3) ^ ((-(pp >> 2)) & 3);
@@ -240,6 +241,7 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 4 : 1) void ggp_kernel(const vg
     issue_patch_round(0, 0);
     issue_patch_round(0, 1);
     issue_patch_round(0, 2);
+    if constexpr (NR == 4) issue_patch_round(0, 3);
     patch_advance();
     if constexpr (TPS == 2) {
         // ---- two taps per barrier, two weight slots: everything issued during a stage is drained at the next ----
@@ -255,7 +257,11 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 4 : 1) void ggp_kernel(const vg
                 __builtin_amdgcn_s_barrier();
                 if (more_p) {
                     if (h == 0) { issue_patch_round(pb ^ 1, 0); issue_patch_round(pb ^ 1, 1); }
-                    else { issue_patch_round(pb ^ 1, 2); patch_advance(); }
+                    else {
+                        issue_patch_round(pb ^ 1, 2);
+                        if constexpr (NR == 4) issue_patch_round(pb ^ 1, 3);
+                        patch_advance();
+                    }
                 }
                 if (s + 1 < S2) issue_b(bb ^ 1);
                 compute(pb, bb, 2 * h);
@@ -411,7 +417,7 @@ inline bool patch_geometry(const vg_gg_desc* d, int bm, PatchGeo* g) {
     if (GH * GW >= bm) { IMGS = 1; R = bm / GW; if (R < 1 || GH % R) return false; }
     else { IMGS = bm / (GH * GW); R = GH; }
     g->R = R; g->IMGS = IMGS; g->PW = GW + 1; g->PIMG = (R + 1) * (GW + 1); g->NPP = IMGS * g->PIMG;
-    if (g->NPP > (bm == 256 ? 384 : 192)) return false;
+    if (g->NPP > (bm == 256 ? 384 : (GP_TPS == 2 ? 256 : 192))) return false;
     g->ncy = d->TH / 2; g->ncx = d->TW / 2; g->nct = d->IC / 32;
     return true;
 }
