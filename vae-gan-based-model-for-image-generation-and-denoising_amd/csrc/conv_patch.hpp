@@ -41,17 +41,17 @@ __device__ __forceinline__ void gp_wait(int n) {
 
 // WM = 2: 128-row tile, 4 waves, patch <= 192 pixels, 48.5 KB LDS (3 workgroups per CU).
 // WM = 4: 256-row tile, 8 waves sharing every weight tile (half the weight traffic per FLOP), patch <= 384 pixels,
-//         73 KB LDS (2 workgroups = 16 waves per CU -> 128 registers per wave).  MEASURED SLOWER than WM = 2 on
-//         MI355X (G3 dgrad 542 vs 800, G4 dgrad 553 vs 747 TFLOP/s): the register cap spills (36 dwords) and drops
-//         the hoisted fragment addresses.  Kept selectable (VG_PATCH256_MIN=<min tiles>) as the starting point for a
-//         leaner 8-wave kernel; never chosen by default.
+//         all four taps of a chunk per barrier, 113 KB LDS: ONE workgroup (8 waves, up to 256 registers each) per CU.
+//         History: with a 128-register cap (two workgroups per CU) it spilled and lost 30 %; at one workgroup per CU
+//         with two taps per barrier it was on par; with four taps per barrier it wins where the launch has >= 384
+//         tiles (G3 fprop 742 -> 780, G4 dgrad 689 -> 750 TFLOP/s) and loses at 256 tiles (G2 fprop 835 -> 806).
 template <int WM, int BN = GP_BN>
-__global__ __launch_bounds__(128 * WM, WM == 4 ? 4 : 1) void ggp_kernel(const vg_gg_desc d, const PatchGeo g) {
+__global__ __launch_bounds__(128 * WM, WM == 4 ? 2 : 1) void ggp_kernel(const vg_gg_desc d, const PatchGeo g) {
     // BN = 128: wave tile 64 x 64; BN = 64 (layers with <= 64 output channels): wave tile 64 x 32
     constexpr int BM = 64 * WM, WN = 2, TM = 4, TN = BN / 32, NT = 128 * WM, BST = BN * 64, WNC = BN / 2;
-    constexpr int NR = (WM == 4 || GP_TPS != 2) ? 3 : 4;   // patch DMA rounds: 192 (3) or 256 (4) pixels per 128 rows
+    constexpr int NR = (WM == 4 || GP_TPS != 2) ? 3 : 4;   /* WM == 4: 3 rounds of 512 lanes = 384 pixels */   // patch DMA rounds: 192 (3) or 256 (4) pixels per 128 rows
     constexpr int GP_PBUF = NR * NT * 16;           // NR rounds of NT lanes x 16 B
-    constexpr int TPS = WM == 4 ? 1 : GP_TPS;      // the 8-wave variant keeps 1 tap x 3 slots (LDS)
+    constexpr int TPS = (WM == 4 && GP_TPS == 2) ? 4 : GP_TPS;   // 8 waves, one workgroup per CU: all 4 taps per barrier
     constexpr int NB = TPS == 2 ? 2 : 3, BSTAGE = TPS * BST;
     constexpr int BJ = (BN * 4) / NT;               // weight-tile DMA instructions per wave and tap (2 / 1)
     static_assert(BN == 128 || (BN == 64 && WM == 2), "supported shapes");
@@ -181,13 +181,7 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 4 : 1) void ggp_kernel(const vg
     auto compute = [&](int pb, int bb, int k) {
         const int a = k >> 1, b = k & 1;
         const int shy = a ? sh_y1 : 1 - sh_y1, shx = b ? sh_x1 : 1 - sh_x1;
-        int tapoff = shy * g.PW + shx;
-        if constexpr (WM == 4) {
-            // 8-wave variant only: keep the four taps' fragment addresses from being hoisted out of the chunk loop
-            // (16 address VGPRs live across the whole kernel spill under its 128-register cap).  The 4-wave variant
-            // WANTS them hoisted: recomputing them per stage cost it 10 %.
-            asm volatile("" : "+s"(tapoff));
-        }
+        const int tapoff = shy * g.PW + shx;
         const unsigned char* sa = pbuf + pb * GP_PBUF;
         const unsigned char* sb = bring + bb * BSTAGE + (k % TPS) * BST;
         u32x4 fa[TM], fb[TN];
@@ -243,29 +237,28 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 4 : 1) void ggp_kernel(const vg
     issue_patch_round(0, 2);
     if constexpr (NR == 4) issue_patch_round(0, 3);
     patch_advance();
-    if constexpr (TPS == 2) {
-        // ---- two taps per barrier, two weight slots: everything issued during a stage is drained at the next ----
+    if constexpr (TPS >= 2) {
+        // ---- TPS taps per barrier, two weight slots: everything issued during a stage is drained at the next ----
+        constexpr int SPC = 4 / TPS;                            // stages per chunk
         issue_b(0);
-        const int S2 = J * 2;
+        const int S2 = J * SPC;
         int bb = 0, s = 0;
         for (int j = 0; j < J; ++j) {
             const int pb = j & 1;
             const bool more_p = j + 1 < J;
 #pragma unroll
-            for (int h = 0; h < 2; ++h, ++s) {
+            for (int h = 0; h < SPC; ++h, ++s) {
                 VG_WAITCNT_VM(0);
                 __builtin_amdgcn_s_barrier();
                 if (more_p) {
-                    if (h == 0) { issue_patch_round(pb ^ 1, 0); issue_patch_round(pb ^ 1, 1); }
-                    else {
-                        issue_patch_round(pb ^ 1, 2);
-                        if constexpr (NR == 4) issue_patch_round(pb ^ 1, 3);
-                        patch_advance();
-                    }
+#pragma unroll
+                    for (int r = 0; r < NR; ++r)
+                        if (r >= (h * NR) / SPC && r < ((h + 1) * NR) / SPC) issue_patch_round(pb ^ 1, r);
+                    if (h == SPC - 1) patch_advance();
                 }
                 if (s + 1 < S2) issue_b(bb ^ 1);
-                compute(pb, bb, 2 * h);
-                compute(pb, bb, 2 * h + 1);
+#pragma unroll
+                for (int t = 0; t < TPS; ++t) compute(pb, bb, h * TPS + t);
                 bb ^= 1;
             }
         }
