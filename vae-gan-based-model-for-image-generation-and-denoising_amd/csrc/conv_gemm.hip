@@ -626,6 +626,8 @@ inline TileCfg pick_tile(const vg_gg_desc* d, bool bf16 = false) {
     if (N <= 32) return {128, 32};
     // 256 x 128 exists only as the patch kernel (bf16, LDS-DMA): 8 waves share every weight tile
     PatchGeo pg;
+    // (a 256 x 64 instantiation for N <= 64 exists -- ggp_kernel<4, 64> -- but measured no better than 128 x 64
+    // on the step, so it is not selected)
     if (bf16 && N > 64 && use_patch() && use_dma() && d->zeros != nullptr &&
         tiles_of(M, N, 256, 128) * ph >= patch256_min() && patch_geometry(d, 256, &pg))
         return {256, 128};
@@ -744,15 +746,16 @@ extern "C" int vg_gather_gemm(const vg_gg_desc* d, int dtype, void* stream) {
     }
     if (dtype == VG_F32) return dispatch<VG_F32>(d, t, vg_stream(stream), sk);
     PatchGeo pg;
-    if ((t.bm == 128 || t.bm == 256) && (t.bn == GP_BN || (t.bn == 64 && t.bm == 128 && patch64())) && sk.ksplit <= 1 &&
+    if ((t.bm == 128 || t.bm == 256) && (t.bn == GP_BN || (t.bn == 64 && patch64())) && sk.ksplit <= 1 &&
         use_patch() && use_dma() && d->zeros != nullptr && patch_geometry(d, t.bm, &pg)) {
         const int m_tiles = (d->B * d->GH * d->GW) / t.bm, n_tiles = (d->N + t.bn - 1) / t.bn;
         dim3 grid(((m_tiles + 7) / 8) * 8 * n_tiles, 1, d->nphase);
-        if (t.bm == 256) vg_launch_timed(0, ggp_kernel<4>, grid, dim3(512), 0, vg_stream(stream), *d, pg);
+        if (t.bm == 256 && t.bn == 64) vg_launch_timed(0, (ggp_kernel<4, 64>), grid, dim3(512), 0, vg_stream(stream), *d, pg);
+        else if (t.bm == 256) vg_launch_timed(0, ggp_kernel<4>, grid, dim3(512), 0, vg_stream(stream), *d, pg);
         else if (t.bn == 64) vg_launch_timed(0, (ggp_kernel<2, 64>), grid, dim3(256), 0, vg_stream(stream), *d, pg);
         else vg_launch_timed(0, ggp_kernel<2>, grid, dim3(256), 0, vg_stream(stream), *d, pg);
         return VG_LAUNCH_RC();
     }
-    if (t.bm == 256 && t.bn == 128) return VG_EINVAL;      // (env flipped between planning and launch)
+    if (t.bm == 256 && t.bn >= 64) return VG_EINVAL;       // (env flipped between planning and launch)
     return dispatch<VG_BF16>(d, t, vg_stream(stream), sk);
 }

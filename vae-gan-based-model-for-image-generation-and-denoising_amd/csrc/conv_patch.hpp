@@ -53,8 +53,12 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 2 : 1) void ggp_kernel(const vg
     constexpr int GP_PBUF = NR * NT * 16;           // NR rounds of NT lanes x 16 B
     constexpr int TPS = (WM == 4 && GP_TPS == 2) ? 4 : GP_TPS;   // 8 waves, one workgroup per CU: all 4 taps per barrier
     constexpr int NB = TPS == 2 ? 2 : 3, BSTAGE = TPS * BST;
-    constexpr int BJ = (BN * 4) / NT;               // weight-tile DMA instructions per wave and tap (2 / 1)
-    static_assert(BN == 128 || (BN == 64 && WM == 2), "supported shapes");
+    constexpr int BJ = (BN * 4 + NT - 1) / NT;      // weight-tile DMA instructions per wave and tap (2 / 1)
+    // 256 x 64: the 64-row weight tile needs only 256 of the 512 lanes -> waves 4-7 skip the weight DMA (legal here:
+    // that variant never uses counted vmcnt waits, every stage drains with vmcnt(0))
+    constexpr bool B_HALF = (BN * 4 < NT);
+    static_assert(BN == 128 || BN == 64, "supported shapes");
+    static_assert(!B_HALF || TPS >= 2, "partial weight issue needs the drain-every-stage loop");
     // [patch buffers 2 x 12|24 KB][weight ring 3 x 8 KB][output-pixel table]
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * GP_PBUF + NB * BSTAGE + BM * 4];
     unsigned char* const pbuf = smem;
@@ -147,12 +151,14 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 2 : 1) void ggp_kernel(const vg
             const int py = bs_cl / g.ncx, px = bs_cl - py * g.ncx;
             const int t = ((bs_k >> 1) * g.ncy + py) * d.TW + ((bs_k & 1) * g.ncx + px);
             const uint32_t koff = ((uint32_t)t * (uint32_t)d.IC + (uint32_t)bs_c * 32u) * 2u;
+            if (!(B_HALF && wave_u >= (BN * 4) / 64)) {
 #pragma unroll
-            for (int j = 0; j < BJ; ++j) {
-                const unsigned char* src = b_base[j] + (b_live[j] ? koff : 0u);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(bring + buf * BSTAGE + tp * BST + ((NT / 4) * j + 16 * wave_u) * 64),
-                                                 16, 0, 0);
+                for (int j = 0; j < BJ; ++j) {
+                    const unsigned char* src = b_base[j] + (b_live[j] ? koff : 0u);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(bring + buf * BSTAGE + tp * BST + ((NT / 4) * j + 16 * wave_u) * 64),
+                                                     16, 0, 0);
+                }
             }
             if (++bs_k == 4) { bs_k = 0; if (++bs_c == g.nct) { bs_c = 0; ++bs_cl; } }
         }
