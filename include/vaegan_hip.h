@@ -240,6 +240,11 @@ int vg_nhwc_to_nchw(const void* x, float* y, int B, int C, int H, int W, int CP,
 /* Gradient of the above: dy NCHW f32 -> dx NHWC dtype, optionally * (1 - t*t) with t = tanh output (NCHW f32). */
 int vg_nchw_grad_to_nhwc(const float* dy, const float* tanh_out, void* dx,
                          int B, int C, int H, int W, int CP, int dtype, void* stream);
+/* Same with a second gradient branch that already sits in the engine layout: dx = (dy + add_nhwc) * (1 - t*t).
+ * vaegan_code.py:117,133: the reconstruction's gradient is d(MSE)/d(recon) (NCHW f32) plus the Discriminator's
+ * input gradient through the instance-noise add (NHWC) -- one pass instead of layout change + add + layout change. */
+int vg_nchw_grad_add_to_nhwc(const float* dy, const void* add_nhwc, const float* tanh_out, void* dx,
+                             int B, int C, int H, int W, int CP, int dtype, void* stream);
 /* Reparameterisation (vaegan_code.py:75-77): lv=clamp(logvar,-10,10); z=mu+exp(.5 lv)*eps.
  * mulv: [B][MP] dtype, the fused fc_mu|fc_logvar output (main_vae.py:55-56): columns [0,L) = mu,
  * [L,2L) = logvar.  eps: [B][L] f32.  z: [B][ZP] dtype (pad = 0).  lv_clamped: [B][L] f32. */

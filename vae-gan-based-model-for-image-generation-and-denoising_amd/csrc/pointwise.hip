@@ -75,12 +75,15 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const void* __restric
 template <int DT>
 __global__ __launch_bounds__(256) void nchw_grad_to_nhwc_kernel(const float* __restrict__ dy,
                                                                 const float* __restrict__ t, void* __restrict__ dx,
-                                                                int64_t npix, int C, int HW, int CP) {
+                                                                int64_t npix, int C, int HW, int CP,
+                                                                const void* __restrict__ add) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t b = i / HW;
         const int64_t hw = i - b * HW;
         for (int c0 = 0; c0 < CP; c0 += 4) {
             float v[4];
+            float a[4] = {0.f, 0.f, 0.f, 0.f};
+            if (add) { const float4 q = load4<DT>(add, i * CP + c0); a[0] = q.x; a[1] = q.y; a[2] = q.z; a[3] = q.w; }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int c = c0 + k;
@@ -88,6 +91,7 @@ __global__ __launch_bounds__(256) void nchw_grad_to_nhwc_kernel(const float* __r
                 if (c < C) {
                     const int64_t src = (b * C + c) * HW + hw;
                     v[k] = dy[src];
+                    if (add) v[k] = v[k] + a[k];          // second gradient branch, already in the engine layout
                     if (t) { const float tv = t[src]; v[k] = v[k] * (1.f - tv * tv); }
                 }
             }
@@ -449,13 +453,23 @@ extern "C" int vg_nhwc_to_nchw(const void* x, float* y, int B, int C, int H, int
     return VG_LAUNCH_RC();
 }
 
+extern "C" int vg_nchw_grad_add_to_nhwc(const float* dy, const void* add_nhwc, const float* tanh_out, void* dx, int B,
+                                        int C, int H, int W, int CP, int dtype, void* stream) {
+    CHECK_DT();
+    VG_CHECK_ARG(dy && add_nhwc && dx && B > 0 && C > 0 && H > 0 && W > 0 && CP >= C && CP % 4 == 0, VG_EINVAL);
+    const int64_t npix = (int64_t)B * H * W;
+    DISPATCH_DT(nchw_grad_to_nhwc_kernel, dim3(blocks_for(npix)), dim3(256), vg_stream(stream), dy, tanh_out, dx, npix,
+                C, H * W, CP, add_nhwc);
+    return VG_LAUNCH_RC();
+}
+
 extern "C" int vg_nchw_grad_to_nhwc(const float* dy, const float* tanh_out, void* dx, int B, int C, int H, int W,
                                     int CP, int dtype, void* stream) {
     CHECK_DT();
     VG_CHECK_ARG(dy && dx && B > 0 && C > 0 && H > 0 && W > 0 && CP >= C && CP % 4 == 0, VG_EINVAL);
     const int64_t npix = (int64_t)B * H * W;
     DISPATCH_DT(nchw_grad_to_nhwc_kernel, dim3(blocks_for(npix)), dim3(256), vg_stream(stream), dy, tanh_out, dx, npix,
-                C, H * W, CP);
+                C, H * W, CP, (const void*)nullptr);
     return VG_LAUNCH_RC();
 }
 

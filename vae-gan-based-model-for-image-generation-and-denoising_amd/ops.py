@@ -380,6 +380,18 @@ def nhwc_to_nchw(x, C, dtype, apply_tanh=False):
     return y
 
 
+def nchw_grad_add_to_nhwc(dy, add_nhwc, tanh_out, CP, dtype):
+    """dx NHWC = (dy NCHW f32 + add_nhwc) * (1 - tanh_out^2): two gradient branches of the reconstruction in one pass."""
+    _need_cuda(dy, add_nhwc, tanh_out)
+    B, C, H, W = dy.shape
+    if add_nhwc.numel() != B * H * W * CP:
+        raise RuntimeError("nchw_grad_add_to_nhwc: add_nhwc must be [B,H,W,CP]")
+    dx = empty_act((B, H, W, CP), dtype, dy.device)
+    L.check(L.load().vg_nchw_grad_add_to_nhwc(dy.data_ptr(), add_nhwc.data_ptr(), L.ptr(tanh_out), dx.data_ptr(), B, C, H, W,
+                                              CP, dtype, L.stream_ptr()), "vg_nchw_grad_add_to_nhwc")
+    return dx
+
+
 def nchw_grad_to_nhwc(dy, tanh_out, CP, dtype):
     _need_cuda(dy, tanh_out)
     B, C, H, W = dy.shape

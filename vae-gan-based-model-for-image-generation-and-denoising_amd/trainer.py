@@ -126,9 +126,8 @@ class VAEGANTrainer:
         self.opt_E.zero_grad(memset=False)
         self.opt_G.zero_grad(memset=False)
         d_noisy = D._engine.backward(c_adv, dp_adv, True, sink, param_grads=not self.elide_dead_grads)
-        d_img = ops.nhwc_to_nchw(d_noisy, Gn.nc, dt)
-        ops.axpy(d_recon, d_img, 1.0, out=d_recon)
-        d_pre = ops.nchw_grad_to_nhwc(d_recon, recon, G.padc(Gn.nc, dt), dt)
+        # d total / d recon = d MSE + d adv through the instance-noise add (:92), then through tanh: one pass
+        d_pre = ops.nchw_grad_add_to_nhwc(d_recon, d_noisy, recon, G.padc(Gn.nc, dt), dt)
         dz = Gn._engine.backward(ctxG, d_pre, True, sink)
         if self.reducer is not None:
             self._cut(lambda: self.reducer.reduce_async(self.opt_G))     # overlaps with the encoder's backward
