@@ -237,6 +237,10 @@ int vg_noisy_clamp_to_nhwc(const float* x, const float* eps, float sigma, float 
 /* NHWC dtype -> NCHW f32, optional tanh (gan_code.py:50). */
 int vg_nhwc_to_nchw(const void* x, float* y, int B, int C, int H, int W, int CP,
                     int apply_tanh, int dtype, void* stream);
+/* The Generator's output in one pass (vaegan_code.py:83,92): y_nchw = tanh(x) (NCHW f32) and
+ * y_noisy_nhwc = tanh(x) + sigma*eps (NHWC dtype, padded channels 0), eps NCHW f32. */
+int vg_nhwc_tanh_to_nchw_noisy(const void* x, float* y_nchw, const float* eps, float sigma, void* y_noisy_nhwc,
+                               int B, int C, int H, int W, int CP, int dtype, void* stream);
 /* Gradient of the above: dy NCHW f32 -> dx NHWC dtype, optionally * (1 - t*t) with t = tanh output (NCHW f32). */
 int vg_nchw_grad_to_nhwc(const float* dy, const float* tanh_out, void* dx,
                          int B, int C, int H, int W, int CP, int dtype, void* stream);

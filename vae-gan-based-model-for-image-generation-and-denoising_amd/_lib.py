@@ -92,6 +92,7 @@ SIGNATURES = {
     "vg_noisy_clamp_to_nhwc": (c_int, [_P, _P, _F, _F, _F, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "vg_nhwc_to_nchw": (c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "vg_nchw_grad_to_nhwc": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "vg_nhwc_tanh_to_nchw_noisy": (c_int, [_P, _P, _P, _F, _P, _I, _I, _I, _I, _I, _I, _P]),
     "vg_nchw_grad_add_to_nhwc": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "vg_reparam_forward": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "vg_kl_forward": (c_int, [_P, _P, _I, _I, _I, _F, _P, _I, _P]),

@@ -72,6 +72,35 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const void* __restric
     }
 }
 
+// Generator output in one pass (vaegan_code.py:83,92): recon = tanh(pre) as NCHW f32 (for the MSE and tanh') AND
+// recon_noisy = recon + sigma * eps in the Discriminator's NHWC input layout.
+template <int DT>
+__global__ __launch_bounds__(256) void nhwc_tanh_noisy_kernel(const void* __restrict__ x, float* __restrict__ y,
+                                                              const float* __restrict__ eps, float sigma,
+                                                              void* __restrict__ yn, int64_t npix, int C, int HW,
+                                                              int CP) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / HW;
+        const int64_t hw = i - b * HW;
+        for (int c0 = 0; c0 < CP; c0 += 4) {
+            const float4 q = load4<DT>(x, i * CP + c0);
+            const float v[4] = {q.x, q.y, q.z, q.w};
+            float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = c0 + k;
+                if (c < C) {
+                    const int64_t dst = (b * C + c) * HW + hw;
+                    const float t = tanhf(v[k]);
+                    y[dst] = t;
+                    o[k] = t + sigma * eps[dst];
+                }
+            }
+            store4<DT>(yn, i * CP + c0, float4{o[0], o[1], o[2], o[3]});
+        }
+    }
+}
+
 template <int DT>
 __global__ __launch_bounds__(256) void nchw_grad_to_nhwc_kernel(const float* __restrict__ dy,
                                                                 const float* __restrict__ t, void* __restrict__ dx,
@@ -450,6 +479,17 @@ extern "C" int vg_nhwc_to_nchw(const void* x, float* y, int B, int C, int H, int
     const int64_t npix = (int64_t)B * H * W;
     DISPATCH_DT(nhwc_to_nchw_kernel, dim3(blocks_for(npix)), dim3(256), vg_stream(stream), x, y, npix, C, H * W, CP,
                 apply_tanh);
+    return VG_LAUNCH_RC();
+}
+
+extern "C" int vg_nhwc_tanh_to_nchw_noisy(const void* x, float* y_nchw, const float* eps, float sigma, void* y_noisy_nhwc,
+                                          int B, int C, int H, int W, int CP, int dtype, void* stream) {
+    CHECK_DT();
+    VG_CHECK_ARG(x && y_nchw && eps && y_noisy_nhwc && B > 0 && C > 0 && H > 0 && W > 0 && CP >= C && CP % 4 == 0,
+                 VG_EINVAL);
+    const int64_t npix = (int64_t)B * H * W;
+    DISPATCH_DT(nhwc_tanh_noisy_kernel, dim3(blocks_for(npix)), dim3(256), vg_stream(stream), x, y_nchw, eps, sigma,
+                y_noisy_nhwc, npix, C, H * W, CP);
     return VG_LAUNCH_RC();
 }
 

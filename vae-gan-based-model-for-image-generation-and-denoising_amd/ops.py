@@ -380,6 +380,18 @@ def nhwc_to_nchw(x, C, dtype, apply_tanh=False):
     return y
 
 
+def nhwc_tanh_to_nchw_noisy(x, C, eps, sigma, out_noisy, dtype):
+    """x NHWC (pre-tanh) -> (tanh(x) as NCHW f32, tanh(x) + sigma*eps written into out_noisy [B,H,W,CP])."""
+    _need_cuda(x, eps, out_noisy)
+    B, H, W, CP = x.shape
+    if out_noisy.numel() != x.numel() or eps.numel() != B * C * H * W:
+        raise RuntimeError("nhwc_tanh_to_nchw_noisy: shape mismatch")
+    y = torch.empty(B, C, H, W, dtype=torch.float32, device=x.device)
+    L.check(L.load().vg_nhwc_tanh_to_nchw_noisy(x.data_ptr(), y.data_ptr(), eps.data_ptr(), sigma, out_noisy.data_ptr(),
+                                                B, C, H, W, CP, dtype, L.stream_ptr()), "vg_nhwc_tanh_to_nchw_noisy")
+    return y
+
+
 def nchw_grad_add_to_nhwc(dy, add_nhwc, tanh_out, CP, dtype):
     """dx NHWC = (dy NCHW f32 + add_nhwc) * (1 - tanh_out^2): two gradient branches of the reconstruction in one pass."""
     _need_cuda(dy, add_nhwc, tanh_out)

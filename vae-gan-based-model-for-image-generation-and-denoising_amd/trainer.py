@@ -84,7 +84,6 @@ class VAEGANTrainer:
         ZP = G.padc(Gn.nz, dt)
         z, lvc = ops.reparam_forward(mulv, eps_z, L, ZP, dt)
         pre, ctxG = Gn.engine_forward(z, B)
-        recon = ops.nhwc_to_nchw(pre, Gn.nc, dt, apply_tanh=True)
 
         # ---- instance noise, drawn once per step (:91-92); produced directly in the layout D reads.  Both noisy
         # batches live in one [2B] buffer so that a Discriminator iteration can run real+fake as ONE grouped pass
@@ -92,7 +91,12 @@ class VAEGANTrainer:
         CP = G.padc(D.nc, dt)
         both = ops.empty_act((2 * B, real.shape[2], real.shape[3], CP), dt, dev)
         real_noisy = ops.nchw_to_nhwc(real, CP, dt, eps=eps_real, sigma=self.sigma, out=both[:B])
-        recon_noisy = ops.nchw_to_nhwc(recon, CP, dt, eps=eps_recon, sigma=self.sigma, out=both[B:])
+        if Gn.nc == D.nc and pre.shape[-1] == CP:
+            recon = ops.nhwc_tanh_to_nchw_noisy(pre, Gn.nc, eps_recon, self.sigma, both[B:], dt)     # :83 and :92 in one pass
+            recon_noisy = both[B:]
+        else:
+            recon = ops.nhwc_to_nchw(pre, Gn.nc, dt, apply_tanh=True)
+            recon_noisy = ops.nchw_to_nhwc(recon, CP, dt, eps=eps_recon, sigma=self.sigma, out=both[B:])
         grouped = self.group_d_passes and D._engine.can_group(B, 2, both)
 
         # ---- Discriminator updates (:95-105) ----
