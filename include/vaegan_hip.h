@@ -84,6 +84,9 @@ typedef struct vg_gg_desc {
     int64_t ws_bytes;
     const void* zeros;        /* >= 64 zero bytes, 16-byte aligned: source of out-of-image taps on the LDS-DMA path
                                  (NULL selects the register-staged path)       */
+    int32_t act;              /* VG_ACT_*: activation applied in the epilogue (layers WITHOUT BatchNorm, e.g. the
+                                 Discriminator's first Conv2d + LeakyReLU(0.2), gan_code.py:61-62); not with `stats` */
+    float   act_slope;
 } vg_gg_desc;
 
 /* Number of stats slabs vg_gather_gemm will write for this descriptor (host-only query). */

@@ -33,7 +33,8 @@ class GGDesc(Structure):
                 ("N", c_int32), ("Kp", c_int32),
                 ("OH", c_int32), ("OW", c_int32), ("OC", c_int32), ("OSY", c_int32), ("OSX", c_int32),
                 ("ooy", _I4), ("oox", _I4),
-                ("nphase", c_int32), ("stats_capacity", c_int32), ("ws", c_void_p), ("ws_bytes", c_int64), ("zeros", c_void_p)]
+                ("nphase", c_int32), ("stats_capacity", c_int32), ("ws", c_void_p), ("ws_bytes", c_int64), ("zeros", c_void_p),
+                ("act", c_int32), ("act_slope", c_float)]
 
 
 class WGDesc(Structure):

@@ -479,6 +479,14 @@ __global__ __launch_bounds__(256) void gg_kernel(const vg_gg_desc d, const int k
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[i][j][r] += biasv[j];
+    if (d.act != VG_ACT_NONE) {                        // activation of a layer without BatchNorm, fused
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = act_fwd(acc[i][j][r], d.act, d.act_slope);
+    }
     __syncthreads();                                   // opix_tab visible; main-loop LDS reads are done
 
     if (d.stats != nullptr) {
@@ -648,6 +656,7 @@ inline int validate(const vg_gg_desc* d, int dtype) {
     VG_CHECK_ARG((d->Kp * esz) % 64 == 0 && d->Kp >= d->TH * d->TW * d->IC, VG_EALIGN);
     VG_CHECK_ARG(vg_aligned16(d->X) && vg_aligned16(d->W) && vg_aligned16(d->Y), VG_EALIGN);
     VG_CHECK_ARG((d->OC * esz) % 16 == 0, VG_EALIGN);
+    VG_CHECK_ARG(d->act == VG_ACT_NONE || ((d->act == VG_ACT_RELU || d->act == VG_ACT_LRELU) && d->stats == nullptr), VG_EINVAL);
     VG_CHECK_ARG((int64_t)d->B * d->GH * d->GW < (1ll << 31), VG_EINVAL);
     VG_CHECK_ARG((int64_t)d->B * d->IH * d->IW < (1ll << 31), VG_EINVAL);
     VG_CHECK_ARG((int64_t)d->B * d->IH * d->IW * d->IC * esz < (1ll << 32), VG_ENOSUP);   // 32-bit gather offsets
@@ -661,7 +670,7 @@ inline SplitK plan_splitk(const vg_gg_desc* d, int dtype, TileCfg t) {
     SplitK r{1, 0, 0};
     const int M = d->B * d->GH * d->GW;
     const bool flat = d->nphase == 1 && d->OSY == 1 && d->OSX == 1 && d->GH == d->OH && d->GW == d->OW;
-    if (!flat || d->stats != nullptr) return r;
+    if (!flat || d->stats != nullptr || d->act != VG_ACT_NONE) return r;
     const int esz = dtype == VG_F32 ? 4 : 2;
     const int kch = dtype == VG_BF16 ? 2 : 1;
     const int nstages = ((d->Kp * esz) / 64 + kch - 1) / kch;

@@ -329,6 +329,14 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 2 : 1) void ggp_kernel(const vg
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[i][j][r] += biasv[j];
+    if (d.act != VG_ACT_NONE) {                        // activation of a layer without BatchNorm, fused
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = act_fwd(acc[i][j][r], d.act, d.act_slope);
+    }
     __syncthreads();                                   // opix_tab visible; main-loop LDS reads are done
 
     if (d.stats != nullptr) {

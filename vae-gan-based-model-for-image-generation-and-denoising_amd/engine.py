@@ -252,8 +252,12 @@ class StackEngine:
             # the "taps folded into N" GEMM has one column per (tap, channel): its epilogue sums are not
             # per-channel, so that (tiny) stage takes its BatchNorm statistics from a separate pass
             epilogue_stats = want_stats and not pk.tap_in_n
+            # a layer without BatchNorm gets its (Leaky)ReLU in the conv epilogue: "Y" is then the ACTIVATED output,
+            # which carries the same sign information the activation's backward needs (slope >= 0)
+            fuse_act = st.bn is None and st.act != VG_ACT_NONE
             Y, stats, nparts = ops.gather_gemm(gg, a, packs[i]["fprop"], dt, bias=packs[i]["bias"],
-                                               want_stats=epilogue_stats, alg=st.alg(B, dt))
+                                               want_stats=epilogue_stats, alg=st.alg(B, dt),
+                                               act=(st.act, st.slope) if fuse_act else None)
             OC = G.padc(st.cout, dt)
             Y = Y.view(B, st.hout, st.hout, OC)
             rows = B * st.hout * st.hout
@@ -270,10 +274,8 @@ class StackEngine:
                     coeffs = ops.bn_eval_coeffs(bn.weight.detach(), bn.bias.detach(), bn.running_mean,
                                                 bn.running_var, BN_EPS)
                 out = ops.bn_act_forward(Y, coeffs, rows, OC, st.act, st.slope, dt)
-            elif st.act != VG_ACT_NONE:
-                out = ops.bn_act_forward(Y, None, rows, OC, st.act, st.slope, dt)
             else:
-                out = Y
+                out = Y                                     # activation (if any) already applied by the epilogue
             if keep:
                 ctx.append({"x": a, "Y": Y, "coeffs": coeffs, "rows": rows, "OC": OC})
             a = out

@@ -148,7 +148,7 @@ def _gg_desc(g: GGSpec, X, Wp, Y, bias, stats, cap) -> L.GGDesc:
 
 
 def gather_gemm(g: GGSpec, X: torch.Tensor, Wp: torch.Tensor, dtype: int, bias: torch.Tensor = None,
-                want_stats: bool = False, out: torch.Tensor = None, alg=None):
+                want_stats: bool = False, out: torch.Tensor = None, alg=None, act=None):
     """Returns (Y [B,OH,OW,OC], stats slabs or None, nparts).  alg = (flops, bytes) of the layer for the timer."""
     _need_cuda(X, Wp, bias, out)
     if X.dtype != TORCH_DT[dtype] or Wp.dtype != TORCH_DT[dtype]:
@@ -170,6 +170,8 @@ def gather_gemm(g: GGSpec, X: torch.Tensor, Wp: torch.Tensor, dtype: int, bias: 
             L.check(nparts, "vg_gather_gemm_nparts")
         stats = WS.get("stats", nparts * 2 * g.N * 4, X.device)
     d = _gg_desc(g, X, Wp, Y, bias, stats, nparts)
+    if act is not None:                      # (code, slope): activation of a BatchNorm-less layer, fused in the epilogue
+        d.act, d.act_slope = act
     wsb = lib.vg_gather_gemm_ws_bytes(byref(d), dtype)
     if wsb > 0:
         ws = WS.get("splitk", wsb, X.device)
