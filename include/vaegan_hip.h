@@ -87,6 +87,12 @@ typedef struct vg_gg_desc {
     int32_t act;              /* VG_ACT_*: activation applied in the epilogue (layers WITHOUT BatchNorm, e.g. the
                                  Discriminator's first Conv2d + LeakyReLU(0.2), gan_code.py:61-62); not with `stats` */
     float   act_slope;
+    /* Fused activation BACKWARD of the layer below (optional; a data-gradient launch whose output Y is
+     * dL/d(activated output) of a BatchNorm-less layer): Y is multiplied by act'(mask_x) on its way out, mask_x being
+     * that layer's (activated) output in the same [B][OH][OW][OC] layout -- saves the separate vg_act_backward pass. */
+    const void* mask_x;
+    int32_t mask_act;
+    float   mask_slope;
 } vg_gg_desc;
 
 /* Number of stats slabs vg_gather_gemm will write for this descriptor (host-only query). */

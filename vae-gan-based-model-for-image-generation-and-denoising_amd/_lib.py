@@ -34,7 +34,8 @@ class GGDesc(Structure):
                 ("OH", c_int32), ("OW", c_int32), ("OC", c_int32), ("OSY", c_int32), ("OSX", c_int32),
                 ("ooy", _I4), ("oox", _I4),
                 ("nphase", c_int32), ("stats_capacity", c_int32), ("ws", c_void_p), ("ws_bytes", c_int64), ("zeros", c_void_p),
-                ("act", c_int32), ("act_slope", c_float)]
+                ("act", c_int32), ("act_slope", c_float),
+                ("mask_x", c_void_p), ("mask_act", c_int32), ("mask_slope", c_float)]
 
 
 class WGDesc(Structure):

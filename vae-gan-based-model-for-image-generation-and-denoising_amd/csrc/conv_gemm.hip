@@ -25,6 +25,26 @@
 
 namespace {
 
+// activation backward fused into a data-gradient epilogue (vg_gg_desc::mask_x): v = dL/d(activated output) segment
+// (16 bytes, storage dtype), x = the layer's activated output at the same place; returns v * act'(x), rounded again
+template <int DT>
+__device__ __forceinline__ u32x4 mask_segment(u32x4 v, const u32x4& x, int act, float slope) {
+    if constexpr (DT == VG_BF16) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float xl = __uint_as_float(x[k] << 16), xh = __uint_as_float(x[k] & 0xffff0000u);
+            const float gl = __uint_as_float(v[k] << 16), gh = __uint_as_float(v[k] & 0xffff0000u);
+            const uint32_t lo = ElemT<VG_BF16>::from_f32(act_bwd(xl, gl, act, slope));
+            const uint32_t hi = ElemT<VG_BF16>::from_f32(act_bwd(xh, gh, act, slope));
+            v[k] = lo | (hi << 16);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = __float_as_uint(act_bwd(__uint_as_float(x[k]), __uint_as_float(v[k]), act, slope));
+    }
+    return v;
+}
+
 #define VG_WAITCNT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 
 // wait until at most n vector-memory operations of this wave are outstanding (n = DMA instructions that may stay
@@ -555,7 +575,10 @@ __global__ __launch_bounds__(256) void gg_kernel(const vg_gg_desc d, const int k
             const int op = opix_tab[pass * PROWS + row];
             const int cb = n0 * ESZ + seg * 16;        // byte offset of this segment inside the output pixel
             if (op >= 0 && cb < oc_bytes) {
-                const u32x4 v = *reinterpret_cast<const u32x4*>(smem + row * CPITCH + seg * 16);
+                u32x4 v = *reinterpret_cast<const u32x4*>(smem + row * CPITCH + seg * 16);
+                if (d.mask_x != nullptr)
+                    v = mask_segment<DT>(v, *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(d.mask_x) +
+                                                                           (int64_t)op * oc_bytes + cb), d.mask_act, d.mask_slope);
                 *reinterpret_cast<u32x4*>(Yb + (int64_t)op * oc_bytes + cb) = v;
             }
         }
@@ -657,6 +680,7 @@ inline int validate(const vg_gg_desc* d, int dtype) {
     VG_CHECK_ARG(vg_aligned16(d->X) && vg_aligned16(d->W) && vg_aligned16(d->Y), VG_EALIGN);
     VG_CHECK_ARG((d->OC * esz) % 16 == 0, VG_EALIGN);
     VG_CHECK_ARG(d->act == VG_ACT_NONE || ((d->act == VG_ACT_RELU || d->act == VG_ACT_LRELU) && d->stats == nullptr), VG_EINVAL);
+    VG_CHECK_ARG(d->mask_x == nullptr || (vg_aligned16(d->mask_x) && (d->mask_act == VG_ACT_RELU || d->mask_act == VG_ACT_LRELU)), VG_EINVAL);
     VG_CHECK_ARG((int64_t)d->B * d->GH * d->GW < (1ll << 31), VG_EINVAL);
     VG_CHECK_ARG((int64_t)d->B * d->IH * d->IW < (1ll << 31), VG_EINVAL);
     VG_CHECK_ARG((int64_t)d->B * d->IH * d->IW * d->IC * esz < (1ll << 32), VG_ENOSUP);   // 32-bit gather offsets
@@ -670,7 +694,7 @@ inline SplitK plan_splitk(const vg_gg_desc* d, int dtype, TileCfg t) {
     SplitK r{1, 0, 0};
     const int M = d->B * d->GH * d->GW;
     const bool flat = d->nphase == 1 && d->OSY == 1 && d->OSX == 1 && d->GH == d->OH && d->GW == d->OW;
-    if (!flat || d->stats != nullptr || d->act != VG_ACT_NONE) return r;
+    if (!flat || d->stats != nullptr || d->act != VG_ACT_NONE || d->mask_x != nullptr) return r;
     const int esz = dtype == VG_F32 ? 4 : 2;
     const int kch = dtype == VG_BF16 ? 2 : 1;
     const int nstages = ((d->Kp * esz) / 64 + kch - 1) / kch;

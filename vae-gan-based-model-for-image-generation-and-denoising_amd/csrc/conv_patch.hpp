@@ -397,7 +397,10 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 2 : 1) void ggp_kernel(const vg
         const int op = opix_tab[row];
         const int cb = n0 * ESZ + seg * 16;
         if (op >= 0 && cb < oc_bytes) {
-            const u32x4 v = *reinterpret_cast<const u32x4*>(smem + row * CPITCH + seg * 16);
+            u32x4 v = *reinterpret_cast<const u32x4*>(smem + row * CPITCH + seg * 16);
+            if (d.mask_x != nullptr)
+                v = mask_segment<VG_BF16>(v, *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(d.mask_x) +
+                                                                            (int64_t)op * oc_bytes + cb), d.mask_act, d.mask_slope);
             *reinterpret_cast<u32x4*>(Yb + (int64_t)op * oc_bytes + cb) = v;
         }
     }

@@ -296,6 +296,7 @@ class StackEngine:
         dA = dout
         side = side_stream(dout.device) if (self.side_wgrad and param_grads) else None
         held = []                           # tensors the side stream reads: kept alive until the join
+        masked = False                      # dA already carries the activation backward of the stage it belongs to
         for i in range(len(self.stages) - 1, -1, -1):
             st, c = self.stages[i], ctx[i]
             want_dx = need_dx or i > 0
@@ -318,10 +319,11 @@ class StackEngine:
                     gg_, gb_, acc_g = None, None, False
                 dY = ops.bn_act_backward(Y, dA, c["coeffs"], rows, OC, rows, st.bn.weight.detach(), st.act, st.slope,
                                          gg_, gb_, acc_g, dt, sync=self.bn_sync)
-            elif st.act != VG_ACT_NONE:
+            elif st.act != VG_ACT_NONE and not masked:
                 dY = ops.act_backward(Y, dA, st.act, st.slope, dt)
             else:
-                dY = dA
+                dY = dA                                     # no activation, or its backward was fused into the dgrad above
+            masked = False
             if param_grads:
                 if side is None:
                     self._param_grads(i, st, c, dY, B, rows, OC, sink)
@@ -332,7 +334,15 @@ class StackEngine:
                     held.append(dY)
             if want_dx:
                 ggd, _ = self.spec(i, B, "dgrad")
-                dX, _, _ = ops.gather_gemm(ggd, dY, packs[i]["dgrad"], dt, alg=st.alg(B, dt))
+                mask = None
+                if i > 0:
+                    pst, pc = self.stages[i - 1], ctx[i - 1]
+                    # the stage below has an activation but no BatchNorm: its backward is a mask on this dgrad's output
+                    if pst.bn is None and pst.act != VG_ACT_NONE and pst.kind != "head" and ggd.N == pst.cout and \
+                            ggd.OC == pc["OC"]:
+                        mask = (pc["Y"], pst.act, pst.slope)
+                        masked = True
+                dX, _, _ = ops.gather_gemm(ggd, dY, packs[i]["dgrad"], dt, alg=st.alg(B, dt), mask=mask)
                 dA = dX.view(c["x"].shape)
             else:
                 dA = None

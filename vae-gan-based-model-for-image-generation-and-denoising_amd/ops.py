@@ -148,7 +148,7 @@ def _gg_desc(g: GGSpec, X, Wp, Y, bias, stats, cap) -> L.GGDesc:
 
 
 def gather_gemm(g: GGSpec, X: torch.Tensor, Wp: torch.Tensor, dtype: int, bias: torch.Tensor = None,
-                want_stats: bool = False, out: torch.Tensor = None, alg=None, act=None):
+                want_stats: bool = False, out: torch.Tensor = None, alg=None, act=None, mask=None):
     """Returns (Y [B,OH,OW,OC], stats slabs or None, nparts).  alg = (flops, bytes) of the layer for the timer."""
     _need_cuda(X, Wp, bias, out)
     if X.dtype != TORCH_DT[dtype] or Wp.dtype != TORCH_DT[dtype]:
@@ -172,6 +172,11 @@ def gather_gemm(g: GGSpec, X: torch.Tensor, Wp: torch.Tensor, dtype: int, bias: 
     d = _gg_desc(g, X, Wp, Y, bias, stats, nparts)
     if act is not None:                      # (code, slope): activation of a BatchNorm-less layer, fused in the epilogue
         d.act, d.act_slope = act
+    if mask is not None:                     # (activated output of the layer below, code, slope): its activation backward, fused
+        mx, mact, mslope = mask
+        if mx.numel() != Y.numel() or mx.dtype != Y.dtype:
+            raise RuntimeError("gather_gemm: mask tensor must be shaped and typed like the output")
+        d.mask_x, d.mask_act, d.mask_slope = mx.data_ptr(), mact, mslope
     wsb = lib.vg_gather_gemm_ws_bytes(byref(d), dtype)
     if wsb > 0:
         ws = WS.get("splitk", wsb, X.device)
