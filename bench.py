@@ -94,6 +94,12 @@ def main():
                     help="skip the D weight gradients of the generator-loss pass that the reference computes and discards")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON result: keep a private handle on it and point fd 1 at stderr, so that
+    # nothing a library prints (RCCL writes its version banner to stdout at communicator creation) can get in front
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -104,8 +110,14 @@ def main():
     local = local % max(ndev, 1)            # rehearsals put several ranks on one card (gloo); the driver uses 1 rank/GPU
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # VAEGAN_FORCE_DIST=1: take the N > 1 code path (process group, reducer, segmented graphs) with a single rank --
+    # the only way to run the RCCL calls themselves on a one-GPU box
+    multi = world > 1 or os.environ.get("VAEGAN_FORCE_DIST") == "1"
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         backend = os.environ.get("VAEGAN_DIST_BACKEND", "nccl")      # "nccl" == RCCL on ROCm
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -126,7 +138,7 @@ def main():
     e.to(dev), g.to(dev), d.to(dev)
     oE, oG, oD = (V.Adam(m.parameters(), lr=2e-4) for m in (e, g, d))
     reducer = None
-    if world > 1:
+    if multi:
         reducer = ddp.GradReducer()
         reducer.attach(oE, oG, oD)
         reducer.broadcast_parameters(oE, oG, oD)
@@ -145,19 +157,19 @@ def main():
     timer = ops.KernelTimer() if (rank == 0 and not use_graph) else None
     ops.set_timer(timer)
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         losses = step_fn(real, epoch, ez, er, ec)
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     ops.set_timer(None)
-    if world > 1:
+    if multi:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -172,7 +184,7 @@ def main():
         torch.cuda.synchronize()
         ops.set_timer(None)
     if rank != 0:
-        if world > 1:
+        if multi:
             dist.destroy_process_group()
         return
 
@@ -212,8 +224,8 @@ def main():
            "roofline": roofline}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(S, B)
-    print(json.dumps(out), flush=True)
-    if world > 1:
+    print(json.dumps(out), file=result_out, flush=True)
+    if multi:
         dist.destroy_process_group()
 
 

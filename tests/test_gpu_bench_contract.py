@@ -36,6 +36,20 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
 
 
+def test_bench_single_rank_rccl_path_keeps_stdout_to_the_json_line():
+    """VAEGAN_FORCE_DIST=1: the N > 1 code path (RCCL process group, flat-buffer all-reduces between hipGraph
+    segments) with one rank.  RCCL prints a version banner to stdout at communicator creation; bench.py must still
+    hand the driver exactly one line."""
+    env = dict(os.environ, VAEGAN_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2", "--batch", "32",
+                        "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["hip_graph"] is True and d["value"] > 0
+
+
 def test_graft_entry_smoke():
     sys.path.insert(0, ROOT)
     import __graft_entry__ as g
