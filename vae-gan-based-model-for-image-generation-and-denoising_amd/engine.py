@@ -360,13 +360,16 @@ class StackEngine:
             ops.wgrad(wg, dY, c["x"], tmp, False, dt, alg=st.alg(B, dt))
             tb = torch.empty(st.cout, dtype=torch.float32, device=dY.device)
             ops.bias_grad(dY, rows, OC, st.cout, tb, False, dt)
+            dsts, srcs = [], []
             for m, sl in ((st.conv, slice(0, N1)), (st.conv2, slice(N1, st.cout))):
                 for prm, src in ((m.weight, tmp[sl]), (m.bias, tb[sl])):
                     g, acc = sink.get(prm)
                     if acc:
                         ops.axpy(g, src.contiguous(), 1.0, out=g)
                     else:
-                        g.copy_(src)
+                        dsts.append(g), srcs.append(src.view(g.shape))
+            if dsts:
+                torch._foreach_copy_(dsts, srcs)            # one multi-tensor launch instead of four device copies
             return
         gw, acc = sink.get(st.conv.weight)
         if st.kind == "conv":
