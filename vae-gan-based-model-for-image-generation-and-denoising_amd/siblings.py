@@ -52,7 +52,7 @@ class _Graphed:
         cap = torch.cuda.Stream(device=sin[0].device)
         cap.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(cap):
-            graph.capture_begin()
+            graph.capture_begin(capture_error_mode="thread_local")   # see trainer.py: other threads (c10d watchdog) may poll events
             sout = self.train_step(*sin, **scalars)
             graph.capture_end()
         torch.cuda.current_stream().wait_stream(cap)

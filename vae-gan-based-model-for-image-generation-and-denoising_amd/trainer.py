@@ -189,7 +189,10 @@ class VAEGANTrainer:
 
         def begin():
             g = torch.cuda.CUDAGraph()
-            g.capture_begin(pool=pool)
+            # thread-local capture mode: torch.distributed's watchdog thread polls finished collectives with
+            # hipEventQuery at its own pace; under the default (global) mode such a call from ANOTHER thread while
+            # this one captures is an error that takes the process down (seen once in four runs with RCCL)
+            g.capture_begin(pool=pool, capture_error_mode="thread_local")
             graphs.append(g)
 
         def cut(collective):                       # close this segment, remember the collective, open the next
