@@ -21,6 +21,10 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+# the host driver of this pool only supports dmabuf IPC: without this RCCL's peer-memory exchange fails with
+# "hipIpcGetMemHandle: invalid argument" (already exported on the GPU boxes; set here in case a launcher drops it)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
