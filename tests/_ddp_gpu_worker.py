@@ -26,7 +26,11 @@ def main():
     lr = float(sys.argv[7])
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    backend = os.environ.get("VAEGAN_TEST_BACKEND", "gloo")       # "nccl" (= RCCL) only with one rank per GPU
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
     try:
         V.configure_seed(42)
         e = V.Encoder([3, S, S], 100)

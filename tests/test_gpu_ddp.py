@@ -27,13 +27,13 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _launch(tmp_path, world, S, GB, steps, sync_bn, graph, lr=2e-4):
-    out = str(tmp_path / f"w{world}_s{sync_bn}_g{graph}.npz")
+def _launch(tmp_path, world, S, GB, steps, sync_bn, graph, lr=2e-4, backend="gloo"):
+    out = str(tmp_path / f"w{world}_s{sync_bn}_g{graph}_{backend}.npz")
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", VAEGAN_TEST_BACKEND=backend)
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_ddp_gpu_worker.py"), out, str(S), str(GB),
                                        str(steps), str(sync_bn), str(graph), repr(lr)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT))
@@ -154,3 +154,24 @@ def test_per_replica_bn_ranks_stay_consistent_eager_and_graphed(tmp_path):
     assert int(eager[0]["stat_collectives"]) == 0
     # BatchNorm buffers are per replica in this mode: the shards differ, so do the running means
     assert not np.array_equal(eager[0]["buf_D.main.3.running_mean"], eager[1]["buf_D.main.3.running_mean"])
+
+
+
+@pytest.mark.parametrize("sync_bn,graph", [(1, 0), (0, 1)])
+def test_single_rank_over_rccl_equals_single_process(tmp_path, sync_bn, graph):
+    """The collectives themselves over RCCL (backend "nccl"), which the shared-GPU gloo tests above cannot reach: one
+    rank per GPU means one rank here.  SyncBN mode (f64 statistics all-reduces inside every BatchNorm, eager) and
+    throughput mode (flat-buffer gradient all-reduces between hipGraph segments, 3 iterations: eager, capture,
+    replay).  With one rank every reduction is the identity, so the run must reproduce the single-process one."""
+    S, GB, steps = 64, 8, (1 if sync_bn else 3)
+    r0 = _launch(tmp_path, 1, S, GB, steps, sync_bn, graph, backend="nccl")[0]
+    one = _single_process(S, GB, steps, 2e-4)
+    tol = [1e-5, 1e-5, 5e-4, 1e-5, 5e-4]           # first iteration (FIRST_STEP_TOL)
+    for i, t in enumerate(tol):
+        assert abs(r0["losses"][0, i] - one["losses"][0, i]) <= t * abs(one["losses"][0, i]), (i, r0["losses"], one["losses"])
+    assert np.isfinite(r0["losses"]).all() and np.isfinite(r0["par_G"]).all()
+    if sync_bn:
+        assert int(r0["stat_collectives"]) > 0
+    for k in one:
+        if k.startswith("buf_") and "num_batches" in k:
+            assert int(r0[k]) == int(one[k]), k
