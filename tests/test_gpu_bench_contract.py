@@ -40,7 +40,11 @@ def test_bench_single_rank_rccl_path_keeps_stdout_to_the_json_line():
     """VAEGAN_FORCE_DIST=1: the N > 1 code path (RCCL process group, flat-buffer all-reduces between hipGraph
     segments) with one rank.  RCCL prints a version banner to stdout at communicator creation; bench.py must still
     hand the driver exactly one line."""
-    env = dict(os.environ, VAEGAN_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, VAEGAN_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2", "--batch", "32",
                         "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
