@@ -156,8 +156,21 @@ def main():
 
     use_graph = bool(args.graph)            # N > 1: segmented graphs, collectives launched between the segments
     step_fn = tr.train_step_graphed if use_graph else tr.train_step
-    for _ in range(max(args.warmup, 2 if use_graph else 0)):
-        step_fn(real, epoch, ez, er, ec)
+    n_warm = max(args.warmup, 2 if use_graph else 0)
+    done = 0
+    try:
+        for done in range(n_warm):
+            step_fn(real, epoch, ez, er, ec)
+        done = n_warm
+    except Exception as ex:                 # noqa: BLE001 -- any capture failure: keep the measurement alive
+        if not use_graph:
+            raise
+        # A failed capture has executed nothing (VAEGANTrainer restores its state); carry on with eager launches.
+        # The collectives per iteration are the same in both modes, so ranks may even differ in mode.
+        print(f"[bench] rank {rank}: hipGraph capture failed ({ex!r}); falling back to eager launches", file=sys.stderr)
+        use_graph, step_fn = False, tr.train_step
+        for _ in range(done, n_warm):
+            step_fn(real, epoch, ez, er, ec)
     timer = ops.KernelTimer() if (rank == 0 and not use_graph) else None
     ops.set_timer(timer)
     torch.cuda.synchronize()
@@ -177,10 +190,11 @@ def main():
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    if use_graph:
+    if args.graph:
         # graph replay: per-launch HIP events cannot be recorded inside captured graphs, so the kernel families are
         # timed in an extra EAGER pass of the same steps after the timed region (every rank runs it: it contains
-        # the collectives; only rank 0 records)
+        # the collectives; only rank 0 records).  Keyed on the REQUESTED mode so that a rank that fell back to
+        # eager launches still takes part in these collectives (its timed-loop recording is simply replaced).
         timer = ops.KernelTimer() if rank == 0 else None
         ops.set_timer(timer)
         for _ in range(args.steps):

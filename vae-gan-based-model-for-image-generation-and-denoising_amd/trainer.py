@@ -200,20 +200,34 @@ class VAEGANTrainer:
             cuts.append(collective)
             begin()
 
+        def restore_host_counters():               # capture only records: undo the host-side counter changes it made
+            for m, t in zip((self.E, self.G, self.D), ticks):
+                m._engine.pending_bn_ticks = t
+            for o, st in zip((self.opt_E, self.opt_G, self.opt_D), steps):
+                o.steps = st
+
         with torch.cuda.stream(cap):
             self._cut_hook = cut
             try:
                 begin()
                 sout = self.train_step(sin[0], epoch, sin[1], sin[2], sin[3])
                 graphs[-1].capture_end()
+            except BaseException:
+                # leave no stream behind in capture mode and no half-built state: nothing was executed, so after
+                # this the trainer is exactly where it was before the call and can run eagerly (or capture again)
+                try:
+                    graphs[-1].capture_end()
+                except Exception:
+                    pass
+                restore_host_counters()
+                self._graph, self._warm_key = None, None
+                for eng in (self.E._engine, self.G._engine, self.D._engine):
+                    eng.invalidate()
+                raise
             finally:
                 self._cut_hook = None
         torch.cuda.current_stream().wait_stream(cap)
-        # capture only records: undo the host-side counter changes it made, then replay for real
-        for m, t in zip((self.E, self.G, self.D), ticks):
-            m._engine.pending_bn_ticks = t
-        for o, st in zip((self.opt_E, self.opt_G, self.opt_D), steps):
-            o.steps = st
+        restore_host_counters()                    # then replay for real
         self._graph = (key, graphs, cuts, sin, sout)
         self._replay(graphs, cuts)
         self._advance_host_counters()
