@@ -35,12 +35,32 @@ PEAK = {"fp32": 157.3, "bf16": 2500.0}          # dense MFMA TFLOP/s, MI355X_MIC
 # --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command; FETCH_SIZE doubled per the gfx950 correction of
 # MI355X_MICROARCH.md section HBM, counters in KiB): measured offline, NOT re-measured by this run.
 def pmc_traffic(dtype):
-    """bytes per gather-GEMM launch from the committed PMC summary (profiles/r01_<dtype>_pmc_traffic.json)."""
-    f = os.path.join(ROOT, "profiles", f"r01_{dtype}_pmc_traffic.json")
+    """(bytes per gather-GEMM launch, source file) from the newest committed PMC summary
+    (profiles/rNN_<dtype>_pmc_traffic.json): measured offline by separate rocprofv3 --pmc passes, not by this run."""
+    for rnd in ("r02", "r01"):
+        f = os.path.join(ROOT, "profiles", f"{rnd}_{dtype}_pmc_traffic.json")
+        try:
+            return round(json.load(open(f))["families"]["gather_gemm"]["hbm_bytes_per_launch"]), os.path.relpath(f, ROOT)
+        except Exception:
+            continue
+    return None, None
+
+
+def cpu_info():
+    model = "unknown"
     try:
-        return round(json.load(open(f))["families"]["gather_gemm"]["hbm_bytes_per_launch"])
-    except Exception:
-        return None
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.lower().startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    return model, avail, os.cpu_count() or avail
 
 
 HBM_PEAK_GBS = 8000.0
@@ -53,30 +73,116 @@ def make_inputs(B, S, seed, latent=100):
         torch.randn(B, 3, S, S, generator=g)
 
 
-def cpu_baseline(S, B, budget_s=25.0):
+def cpu_baseline(S, B, budget_s=20.0):
     """The CPU oracle (bit-checked against the reference classes, tests/golden) timed on this box's host cores:
-    a bounded sample of the same workload.  Reported baseline only."""
+    a bounded sample of the bench workload, plus C1 (S=64, B=16: the reference's own CPU-runnable configuration,
+    BASELINE.md section 3).  Reported baseline only."""
     import vaegan_ref as R
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 32))
+    model, avail, total = cpu_info()
+    cores = max(1, min(avail, 32))            # ATen's CPU conv kernels stop scaling (and oversubscribe) beyond this
     torch.set_num_threads(cores)
-    o = R.RefVAEGAN(img_size=S, seed=42)
-    inp = make_inputs(B, S, 1234)
-    t0 = time.time()
-    o.train_step(*inp, 60)                                   # warm-up (also sizes the sample)
-    warm = time.time() - t0
-    steps = max(1, min(5, int(budget_s / max(warm, 1e-3))))
-    t0 = time.time()
+
+    def sample(S_, B_, budget):
+        o = R.RefVAEGAN(img_size=S_, seed=42)
+        inp = make_inputs(B_, S_, 1234)
+        t0 = time.time()
+        o.train_step(*inp, 60)                                   # warm-up (also sizes the sample)
+        warm = time.time() - t0
+        steps = max(1, min(5, int(budget / max(warm, 1e-3))))
+        t0 = time.time()
+        for _ in range(steps):
+            o.train_step(*inp, 60)
+        return (time.time() - t0) / steps, steps
+
+    dt, steps = sample(S, B, budget_s)
+    out = {"value": round(B / dt, 2), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+           "cpu_model": model, "cores_available": avail, "cores_total": total,
+           "sample": f"{steps} full training steps of S={S} B={B} fp32 after 1 warm-up, CPU oracle "
+                     f"(oracle/vaegan_ref.py, same ATen CPU kernels the reference executes)",
+           "s_per_step": round(dt, 3)}
+    if (S, B) != (64, 16):
+        dt1, st1 = sample(64, 16, 5.0)
+        out["c1"] = {"workload": "S=64 B=16 fp32 (BASELINE configs[0])", "value": round(16 / dt1, 2),
+                     "s_per_step": round(dt1, 3), "steps": st1}
+    return out
+
+
+def build_models(V, S, dtype, dev):
+    V.configure_seed(42)
+    e = V.Encoder([3, S, S], 100, dtype=dtype)
+    g = V.Generator(nz=100, img_size=S, dtype=dtype)
+    d = V.Discriminator(img_size=S, dtype=dtype)
+    g.apply(V.weights_init), d.apply(V.weights_init)
+    e.to(dev), g.to(dev), d.to(dev)
+    return e, g, d
+
+
+def time_steps(fn, warm, steps):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
     for _ in range(steps):
-        o.train_step(*inp, 60)
-    dt = (time.time() - t0) / steps
-    return {"value": round(B / dt, 2), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{steps} full training steps of S={S} B={B} fp32 after 1 warm-up, CPU oracle "
-                      f"(oracle/vaegan_ref.py, same ATen CPU kernels the reference executes)",
-            "s_per_step": round(dt, 3)}
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def parity_path(V, S, B, dev, inputs, steps=10):
+    """The fp32 engine (exact-f32 MFMA; the path whose first-step losses are held to 1e-4 against the reference,
+    tests/test_gpu_parity.py) on the same workload, hipGraph replay."""
+    e, g, d = build_models(V, S, "fp32", dev)
+    tr = V.VAEGANTrainer(e, g, d, *(V.Adam(m.parameters(), lr=2e-4) for m in (e, g, d)))
+    tr.train()
+    dt = time_steps(lambda: tr.train_step_graphed(inputs[0], 60, *inputs[1:]), 3, steps)
+    return {"dtype": "f32", "value": round(B / dt, 1), "unit": "images/sec", "ms_per_step": round(dt * 1e3, 3),
+            "steps": steps, "mode": "VAEGANTrainer.train_step_graphed, injected noise"}
+
+
+def dropin_path(V, S, B, dev, dtype, inputs, steps=10):
+    """the reference trainer's own code shape (vaegan_code.py:65-135 -- module calls, torch
+    ops between them, nn.BCELoss / nn.MSELoss, .backward(), optimizer.step()) on the engine's nn.Modules + Adam:
+    autograd drives the HIP kernel chains, every launch marshalled through ctypes, NCHW<->NHWC at every module edge."""
+    encoder, decoder, discriminator = build_models(V, S, dtype, dev)
+    opt_E, opt_Dec, opt_Dis = (V.Adam(m.parameters(), lr=2e-4) for m in (encoder, decoder, discriminator))
+    bce, mse = torch.nn.BCELoss(), torch.nn.MSELoss(reduction="mean")
+    encoder.train(), decoder.train(), discriminator.train()
+    real_images = inputs[0]
+    epoch, alpha_kl, alpha_adv = 60, 0.1, 0.1
+
+    def step():
+        batch_size = real_images.size(0)
+        mu, logvar = encoder(real_images)
+        logvar = torch.clamp(logvar, min=-10, max=10)
+        std = torch.exp(0.5 * logvar)
+        z = (mu + std * torch.randn_like(std)).unsqueeze(-1).unsqueeze(-1)
+        recon_images = decoder(z)
+        real_labels = torch.full((batch_size,), 0.9, device=dev)
+        fake_labels = torch.full((batch_size,), 0.1, device=dev)
+        real_images_noisy = real_images + 0.05 * torch.randn_like(real_images)
+        recon_images_noisy = recon_images + 0.05 * torch.randn_like(recon_images)
+        for _ in range(2):
+            d_loss = bce(discriminator(real_images_noisy), real_labels) + \
+                bce(discriminator(recon_images_noisy.detach()), fake_labels)
+            opt_Dis.zero_grad()
+            d_loss.backward()
+            opt_Dis.step()
+        fake_output = discriminator(recon_images_noisy)
+        recon_loss = mse(recon_images, real_images)
+        kl_loss = -0.5 * torch.sum(1 + logvar - mu.pow(2) - logvar.exp()) / batch_size
+        g_loss_adv = bce(fake_output, real_labels)
+        total = recon_loss + alpha_kl * min(1.0, epoch / 50) * kl_loss + alpha_adv * g_loss_adv
+        opt_E.zero_grad()
+        opt_Dec.zero_grad()
+        total.backward()
+        opt_E.step()
+        opt_Dec.step()
+        return total
+
+    dt = time_steps(step, 3, steps)
+    return {"dtype": {"fp32": "f32", "bf16": "bf16"}[dtype], "value": round(B / dt, 1), "unit": "images/sec",
+            "ms_per_step": round(dt * 1e3, 3), "steps": steps,
+            "mode": "reference loop on vaegan_amd nn.Modules + Adam (autograd, eager, ctypes binding)"}
 
 
 def main():
@@ -92,6 +198,8 @@ def main():
     ap.add_argument("--dtype", default=os.environ.get("VAEGAN_BENCH_DTYPE", "bf16"), choices=["fp32", "bf16"],
                     help="bf16 = BASELINE configs[1] (bf16 storage, f32 accumulate, fp32 master weights); fp32 = parity path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-paths", action="store_true",
+                    help="skip the secondary legs (fp32 parity path, drop-in autograd path) reported beside the main number")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("VAEGAN_BENCH_GRAPH", "1")),
                     help="1: replay the iteration from captured hipGraph(s); with N > 1 the graph is cut at the all-reduces")
     ap.add_argument("--elide-dead-grads", action="store_true",
@@ -134,12 +242,7 @@ def main():
     ddp = import_module("vae-gan-based-model-for-image-generation-and-denoising_amd.ddp")
 
     S, B = args.size, args.batch
-    V.configure_seed(42)
-    e = V.Encoder([3, S, S], 100, dtype=args.dtype)
-    g = V.Generator(nz=100, img_size=S, dtype=args.dtype)
-    d = V.Discriminator(img_size=S, dtype=args.dtype)
-    g.apply(V.weights_init), d.apply(V.weights_init)
-    e.to(dev), g.to(dev), d.to(dev)
+    e, g, d = build_models(V, S, args.dtype, dev)
     oE, oG, oD = (V.Adam(m.parameters(), lr=2e-4) for m in (e, g, d))
     reducer = None
     if multi:
@@ -149,6 +252,7 @@ def main():
     tr = V.VAEGANTrainer(e, g, d, oE, oG, oD, elide_dead_grads=args.elide_dead_grads, reducer=reducer)
     tr.train()
     real, ez, er, ec = (t.to(dev) for t in make_inputs(B, S, 1234 + rank))
+    resident = (real, ez, er, ec)
     if not args.inject_noise:
         ez = er = ec = None             # vaegan_code.py:77,91,92: randn_like on the device, inside the timed step
         torch.cuda.manual_seed(4242 + rank)     # identical weights on every rank (seed 42), different noise streams
@@ -216,11 +320,18 @@ def main():
     gg = fam.get("gather_gemm", dict(launches=0, ms=1e-9, flops=0, bytes=0))
     wg = fam.get("wgrad", dict(launches=0, ms=1e-9, flops=0, bytes=0))
     ach = gg["flops"] / (gg["ms"] * 1e-3) / 1e12
+    traffic, traffic_src = pmc_traffic(args.dtype)
     roofline = {"bound": "mfma", "kernel": "gg_kernel (gather-GEMM: conv/convT/linear fprop + dgrad)",
                 "achieved": round(ach, 2), "peak": PEAK[args.dtype], "unit": "TFLOP/s",
                 "frac": round(ach / PEAK[args.dtype], 4),
                 # HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/), not re-measured here
-                "traffic": pmc_traffic(args.dtype) if (S, B) == (64, 128) else None,
+                "traffic": traffic if (S, B) == (64, 128) else None,
+                "traffic_source": (f"{traffic_src}: separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of this "
+                                   f"command (FETCH_SIZE doubled, MI355X_MICROARCH.md section HBM), measured offline"
+                                   if (S, B) == (64, 128) and traffic_src else None),
+                "timed_in": ("eager pass after the timed region: HIP start/stop events around every launch on its stream "
+                             "(a replayed hipGraph cannot carry per-launch events)" if args.graph else
+                             "the timed region itself: HIP start/stop events around every launch on its stream"),
                 "launches_per_step": gg["launches"] // args.steps,
                 "avg_launch_us": round(gg["ms"] * 1e3 / max(gg["launches"], 1), 2),
                 "alg_gflop_per_launch": round(gg["flops"] / max(gg["launches"], 1) / 1e9, 3),
@@ -240,6 +351,10 @@ def main():
                       "elide_dead_grads": bool(args.elide_dead_grads), "hip_graph": use_graph},
            "losses": {k: round(v, 5) for k, v in ld.items()},
            "roofline": roofline}
+    if world == 1 and not multi and not args.no_extra_paths:
+        del tr, e, g, d, oE, oG, oD
+        out["parity_path"] = parity_path(V, S, B, dev, resident)
+        out["dropin_path"] = dropin_path(V, S, B, dev, args.dtype, resident)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(S, B)
     print(json.dumps(out), file=result_out, flush=True)

@@ -41,7 +41,7 @@ extern "C" {
 #define VG_ACT_RELU    1   /* nn.ReLU(True)          gan_code.py:23-43            */
 #define VG_ACT_LRELU   2   /* nn.LeakyReLU(slope)    main_vae.py:25, gan_code.py:62-82 */
 
-#define VG_ABI_VERSION 2   /* 2: vg_pack_desc.tile_start, SyncBN / WGAN / data-path entry points */
+#define VG_ABI_VERSION 3   /* 2: vg_pack_desc.tile_start, SyncBN / WGAN / data-path entry points; 3: in-kernel noise (vg_*_rng) */
 int vg_abi_version(void);
 /* Live kernel timing for the roofline report: while enabled, gather-GEMM (family 0) and wgrad (family 1)
  * launches carry a HIP start/stop event pair on their stream (hipExtLaunchKernelGGL); collect() synchronises,
@@ -295,6 +295,33 @@ int vg_mse_forward_backward(const float* a, const float* b, int64_t n, float gsc
  * gaussian 11x11, sigma 1.5, k1 .01, k2 .03, data_range 1, 5-pixel border cropped.  out[0] = mean. */
 int vg_ssim(const float* a, const float* b, int B, int C, int H, int W, float* out, float* ws, int ws_capacity,
             void* stream);
+/* ------------------------------------------------------------------------------------------
+ * In-kernel N(0,1) noise: the three `torch.randn_like` draws of an iteration (vaegan_code.py:77 eps of the
+ * reparameterisation, :91 instance noise on the real batch, :92 on the reconstruction) generated where they are
+ * consumed instead of being materialised by a separate generator launch.
+ * rng: device memory, two 64-bit words {seed, iteration counter}.  Counter-based Philox4x32-10 keyed by the seed;
+ * counter = (element index in the reference's NCHW / [B][L] order, draw id 0..255, iteration counter); Box-Muller.
+ * The `_rng` forms of the consuming kernels are identical to their eps-pointer forms with
+ * eps[i] = N(seed, iteration, draw, i); vg_randn materialises exactly that tensor (tests, and callers that want
+ * the draw itself).  vg_rng_advance (one thread) bumps the iteration counter: launch it once at the top of every
+ * iteration, inside the captured graph, so that every replay draws fresh noise while forward and backward of one
+ * iteration see the same eps.  Device streams can never equal the reference's CPU generator:
+ * parity runs inject host noise through the eps-pointer forms.
+ * ---------------------------------------------------------------------------------------- */
+int vg_rng_advance(uint64_t* rng, void* stream);
+int vg_randn(float* out, int64_t n, const uint64_t* rng, int draw, void* stream);
+int vg_nchw_to_nhwc_rng(const float* x, const uint64_t* rng, int draw, float sigma, void* y,
+                        int B, int C, int H, int W, int CP, int dtype, void* stream);          /* vaegan_code.py:91 */
+int vg_nhwc_tanh_to_nchw_noisy_rng(const void* x, float* y_nchw, const uint64_t* rng, int draw, float sigma,
+                                   void* y_noisy_nhwc, int B, int C, int H, int W, int CP, int dtype,
+                                   void* stream);                                             /* vaegan_code.py:83,92 */
+int vg_reparam_forward_rng(const void* mulv, const uint64_t* rng, int draw, void* z, float* lv_clamped,
+                           int B, int L, int MP, int ZP, int dtype, void* stream);            /* vaegan_code.py:75-78 */
+int vg_reparam_kl_backward_rng(const void* mulv, const float* lv_clamped, const uint64_t* rng, int draw,
+                               const void* dz, float kl_scale, void* dmulv, int B, int L, int MP, int ZP,
+                               int dtype, void* stream);
+/* hipMemsetAsync(p, 0, nbytes) on the stream: optimizer.zero_grad() (vaegan_code.py:103,131-132) over a flat buffer. */
+int vg_memset_zero(void* p, int64_t nbytes, void* stream);
 /* out = a + alpha*b (f32, n elements); used for gradient joins on NCHW images. */
 int vg_axpy(const float* a, const float* b, float alpha, float* out, int64_t n, void* stream);
 /* PSNR/SSIM support for the denoise path lives in vg_image_metrics. */

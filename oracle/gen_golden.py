@@ -195,6 +195,18 @@ def gen_steps(ref):
             losses.append([lr_[n] for n in names])
             out[f"step{step}.recon#stats"], out[f"step{step}.recon#samp"] = tstats(recon)
             out[f"step{step}.real#stats"], _ = tstats(real)
+            if step == 0:
+                # state after the FIRST iteration (not yet chaotic: one Adam step of E and G, two of D, all from the
+                # seed-42 initial state): parameters, BatchNorm buffers and Adam moments.  exp_avg after one step is
+                # (1-beta1)*grad, so these checksums pin the whole backward pass of iteration 1 against the reference.
+                for name, m in (("E", E), ("G", G), ("D", D)):
+                    for k, v in state_stats(m.state_dict()).items():
+                        out[f"after1.{name}.{k}"] = v
+                for name, opt in (("E", oE), ("G", oG), ("D", oD)):
+                    ss = opt.state_dict()["state"]
+                    for i in sorted(ss):
+                        out[f"after1.adam.{name}.{i}.exp_avg#stats"], _ = tstats(ss[i]["exp_avg"])
+                        out[f"after1.adam.{name}.{i}.exp_avg_sq#stats"], _ = tstats(ss[i]["exp_avg_sq"])
         assert_same_state(E.state_dict(), o.E, "E after steps")
         assert_same_state(G.state_dict(), o.G, "G after steps")
         assert_same_state(D.state_dict(), o.D, "D after steps")

@@ -340,6 +340,24 @@ class RefVAEGAN:
         return noisy, recon, float(recon_loss), float(kl)
 
 
+def validation_epoch(model: "RefVAEGAN", batches, noises, alpha_kl: float = 0.1, n_samples=None):
+    """The validation loop of vaegan_code.py:147-191 around RefVAEGAN.denoise (eval-mode E and G):
+    val_loss = sum over batches of (mse_mean + alpha_kl * KL_sum) / number of SAMPLES (:167, :187);
+    SSIM accumulated over all images as torchmetrics' running sums do (:174, :185; restated recipe, parity unpinned);
+    PSNR of the mean squared error over the whole pass (not in the reference).  noises[i] = (sigma*eps, eps_z)."""
+    val, ssim_sum, se_sum, seen = 0.0, 0.0, 0.0, 0
+    for img, (noise, eps_z) in zip(batches, noises):
+        _, recon, rl, kl = model.denoise(img, noise, eps_z)
+        val += rl + alpha_kl * kl
+        a01, b01 = (recon + 1) / 2, (img + 1) / 2
+        ssim_sum += ssim(a01, b01) * img.size(0)
+        se_sum += float(((a01.double() - b01.double()) ** 2).mean()) * img.size(0)
+        seen += img.size(0)
+    n = seen if n_samples is None else n_samples
+    import math
+    return {"val_loss": val / n, "ssim": ssim_sum / seen, "psnr": 10.0 * math.log10(1.0 / (se_sum / seen)), "samples": seen}
+
+
 def configure_seed(seed: int) -> None:
     """utils.py:6-14 (host-side part)."""
     import os

@@ -56,7 +56,9 @@ def main():
         dist.all_reduce(lo)                       # global loss = mean of the per-rank means (equal shards)
         lo /= world
         res = {"losses": lo.cpu().numpy(),
-               "grad_E": (oE.flat_g / world).cpu().numpy(), "grad_G": (oG.flat_g / world).cpu().numpy(),
+               # gradients in named_parameters() order (the flat buffer's placement is the optimizer's business)
+               "grad_E": (torch.cat([p.grad.flatten() for p in e.parameters()]) / world).cpu().numpy(),
+               "grad_G": (torch.cat([p.grad.flatten() for p in g.parameters()]) / world).cpu().numpy(),
                "par_E": oE.flat_p.cpu().numpy(), "par_G": oG.flat_p.cpu().numpy(), "par_D": oD.flat_p.cpu().numpy(),
                "stat_collectives": np.array(red.stat_collectives)}
         for name, net in (("E", e), ("G", g), ("D", d)):

@@ -22,13 +22,18 @@ class _Idx(Dataset):
 
 
 class _FakeResident:
-    """Stands in for ResidentImages on the CPU: DeviceLoader only needs len() for its host logic."""
+    """Stands in for ResidentImages on the CPU: DeviceLoader needs len(), .images.device and .batch(indices); batch()
+    hands the index slice back, so the REAL DeviceLoader.__iter__ can be driven without a GPU."""
 
     def __init__(self, n):
         self.n = n
+        self.images = torch.empty(0)
 
     def __len__(self):
         return self.n
+
+    def batch(self, idx):
+        return idx.tolist()
 
 
 @pytest.mark.parametrize("n,bs", [(103, 8), (64, 64), (10, 3), (1, 4)])
@@ -60,34 +65,39 @@ def test_split_and_epoch_orders_equal_torch_dataloader(n, bs):
     assert torch.equal(torch.rand(3), ref_tail)          # the default RNG stream advanced by exactly as much
 
 
-def test_rank_sharding_partitions_every_global_batch():
-    n, bs, world = 103, 8, 4
+@pytest.mark.parametrize("n,bs,world", [(103, 8, 4), (4 * 8 * 3 + 9, 4, 8), (64, 8, 8), (5, 4, 8), (8 * 4 + 8, 4, 8)])
+def test_rank_sharding_gives_every_rank_the_same_steps_and_rows(n, bs, world):
+    """Drives the real DeviceLoader.__iter__ for every rank.  (B=4, W=8 with 9 left-over samples is the case that
+    used to produce shards [2,2,2,2,1,0,0,0]: a rank without rows never reaches the gradient all-reduce.)"""
     torch.manual_seed(1)
     idx = torch.randperm(n)
     fake = _FakeResident(n)
-
-    class _Rec(D.DeviceLoader):                           # record the index slices instead of gathering on a GPU
-        def __iter__(self):
-            order = self.epoch_order()
-            g = self.batch_size * self.world
-            for start in range(0, order.numel(), g):
-                stop = min(order.numel(), start + g)
-                per = (stop - start + self.world - 1) // self.world
-                if stop - start < self.world:
-                    return
-                yield order[min(stop, start + self.rank * per):min(stop, start + (self.rank + 1) * per)].tolist()
-
     shards = []
     for r in range(world):
         torch.manual_seed(7)
-        shards.append(list(_Rec(fake, idx, bs, shuffle=True, rank=r, world=world)))
+        ld = D.DeviceLoader(fake, idx, bs, shuffle=True, rank=r, world=world)
+        shards.append(list(ld))
+        assert len(ld) == len(shards[-1])
     torch.manual_seed(7)
     whole = D.DeviceLoader(fake, idx, bs * world, shuffle=True).epoch_order().tolist()
     steps = len(shards[0])
-    assert all(len(s) == steps for s in shards) and steps == (n + bs * world - 1) // (bs * world)
+    assert all(len(s) == steps for s in shards)
+    full, rem = divmod(n, bs * world)
+    assert steps == full + (1 if rem >= world else 0)
+    seen = []
     for k in range(steps):
+        rows = {len(shards[r][k]) for r in range(world)}
+        assert len(rows) == 1 and rows.pop() >= 1                 # equal, non-empty shards on every rank
         merged = sum((shards[r][k] for r in range(world)), [])
-        assert merged == whole[k * bs * world:(k + 1) * bs * world]
+        assert merged == whole[k * bs * world:k * bs * world + len(merged)]
+        seen += merged
+    assert n - len(seen) == (rem % world if rem >= world else rem)   # only the unsplittable tail is skipped
+
+
+def test_single_process_loader_keeps_the_ragged_last_batch():
+    fake = _FakeResident(10)
+    got = list(D.DeviceLoader(fake, torch.arange(10), 4, shuffle=False))
+    assert got == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9]]
 
 
 def test_bad_arguments():

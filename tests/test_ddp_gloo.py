@@ -19,10 +19,17 @@ PKG = "vae-gan-based-model-for-image-generation-and-denoising_amd"
 class _FakeOpt:
     """Stands in for optim.Adam on the CPU: the reducer only touches flat_g / flat_p / grad_scale."""
 
-    def __init__(self, n):
+    def __init__(self, n, sizes=None):
         self.flat_g = torch.zeros(n)
         self.flat_p = torch.zeros(n)
         self.grad_scale = 1.0
+        sizes = sizes or [n]
+        self.params, self.offsets, o = [], [], 0
+        for k in sizes:                                     # parameters as views, homed like optim.Adam homes them
+            self.params.append(self.flat_p[o:o + k])
+            self.offsets.append(o)
+            o += (k + 3) // 4 * 4
+        assert o <= n
 
 
 def _d_grads(rank_shard):
@@ -62,8 +69,26 @@ def _worker(rank, world, port, out_dir):
         red.reduce_async(opt2)                              # overlapped reduction ...
         red.reduce(opt)                                     # ... while this one runs
         red.wait(opt2)
+        # bucketed, overlapped form: a "network" of 5 layers whose gradients arrive last layer first; every bucket is
+        # launched at its event, the optimizer waits once at the end.  Must equal ONE all-reduce of the flat buffer.
+        sizes = [1000, 30, 5000, 3, 2001]
+        n3 = sum((k + 3) // 4 * 4 for k in sizes)
+        opt3, opt3_flat = _FakeOpt(n3, sizes), _FakeOpt(n3, sizes)
+        gen = torch.Generator().manual_seed(100 + rank)
+        opt3.flat_g.copy_(torch.randn(n3, generator=gen))
+        opt3_flat.flat_g.copy_(opt3.flat_g)
+        red3 = ddp.GradReducer(bucket_bytes=4 * 1500)
+        plan = red3.plan(opt3, ready=[0, 1, 2, 3, 4])
+        launched = []
+        for ev in (4, 3, 2, 1, 0):                          # backward order
+            launched.append(red3.launch_ready(opt3, ev))
+        assert red3.outstanding() == len(plan)
+        red3.wait(opt3)
+        assert red3.outstanding() == 0
+        red3.reduce(opt3_flat)
         torch.save(dict(avg=opt.flat_g * opt.grad_scale, p=opt.flat_p, small=opt2.flat_g * opt2.grad_scale,
-                        scale=opt.grad_scale, bytes=red.bytes_reduced), os.path.join(out_dir, f"r{rank}.pt"))
+                        scale=opt.grad_scale, bytes=red.bytes_reduced, bucketed=opt3.flat_g, flat=opt3_flat.flat_g,
+                        plan=plan, launched=launched, bytes3=red3.bytes_reduced), os.path.join(out_dir, f"r{rank}.pt"))
     finally:
         dist.destroy_process_group()
 
@@ -86,6 +111,39 @@ def test_grad_reducer_world2_gloo(tmp_path):
         assert torch.equal(o["small"], torch.full((16,), 1.5))
         assert o["bytes"] == (expect.numel() + 16) * 4
     assert torch.equal(outs[0]["avg"], outs[1]["avg"])                     # replicas stay bit-identical
+    for o in outs:
+        assert torch.equal(o["bucketed"], o["flat"])                       # bucketed == flat reduction, bit for bit
+        assert len(o["plan"]) >= 3 and sum(o["launched"]) == len(o["plan"])
+        # one collective per bucket; the whole-buffer reduce of the twin adds the buffer once more
+        assert o["bytes3"] == 2 * o["flat"].numel() * 4
+    assert torch.equal(outs[0]["bucketed"], outs[1]["bucketed"])
+
+
+def test_bucket_plan_covers_the_buffer_in_reverse_layer_order():
+    ddp = importlib.import_module(PKG + ".ddp")
+    # S=64 Discriminator as optim.Adam homes it: conv0, conv1+bn, conv2+bn, conv3+bn, head (floats)
+    sizes = [3072, 131072, 128, 128, 524288, 256, 256, 2097152, 512, 512, 8192]
+    ready = [0, 1, 1, 1, 2, 2, 2, 3, 3, 3, 4]
+    offs, o = [], 0
+    for k in sizes:
+        offs.append(o)
+        o += (k + 3) // 4 * 4
+    plan = ddp.plan_buckets(offs, sizes, ready, o, 8 << 20)
+    assert plan == [(offs[7], o, 3), (0, offs[7], 0)]                      # {D3 + head} leaves first, {D0..D2} at the end
+    covered = sorted((lo, hi) for lo, hi, _ in plan)
+    assert covered[0][0] == 0 and covered[-1][1] == o
+    assert all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+    # a bucket's event is the EARLIEST layer inside it, and launch order follows the backward pass
+    for lo, hi, ev in plan:
+        inside = [ready[i] for i in range(len(sizes)) if lo <= offs[i] < hi]
+        assert ev == min(inside)
+    assert [ev for _, _, ev in plan] == sorted((ev for _, _, ev in plan), reverse=True)
+    # tiny bucket size: one bucket per parameter group, still a partition
+    plan = ddp.plan_buckets(offs, sizes, ready, o, 1)
+    assert sum(hi - lo for lo, hi, _ in plan) == o and len(plan) == len(sizes)
+    # fc_logvar homed behind fc_mu (offsets not in parameter order)
+    plan = ddp.plan_buckets([0, 200, 100, 300], [100, 100, 100, 100], [4, 4, 4, 4], 400, 1 << 30)
+    assert plan == [(0, 400, 4)]
 
 
 def test_reducer_requires_process_group():

@@ -93,3 +93,37 @@ def test_training_from_the_resident_dataset_runs_the_variable_last_batch(jpeg_fo
     torch.cuda.synchronize()
     assert sizes == [16, 16, 8]                                   # 40 training images
     assert all(bool(torch.isfinite(l).all()) for l in losses)
+
+
+def test_validation_epoch_over_the_resident_loader_vs_oracle(jpeg_folder):
+    """vaegan_code.py:147-191: eval-mode E -> G over the validation loader, val_loss = sum(mse + 0.1*KL) / samples,
+    SSIM over all images, the ragged last batch included -- against the oracle's loop on the reference data path's
+    batches (oracle/data_ref.py), identical weights and injected noise."""
+    import vaegan_ref as R
+    from _inputs import make_inputs
+    from test_gpu_parity import sync_from_oracle
+    S = 64
+    torch.manual_seed(42)
+    _, rvl, _ = DR.get_dataset_loaders(jpeg_folder, batch_size=2)
+    ref_batches = [b.clone() for b in rvl]                                   # 5 validation images: 2 + 2 + 1
+    torch.manual_seed(42)
+    _, vl, _ = V.data.get_dataset_loaders(jpeg_folder, batch_size=2, device=DEV, workers=1)
+    e, g, d, tr = build(S)
+    o = R.RefVAEGAN(img_size=S, seed=42)
+    real, ez, er, ec = make_inputs(4, S, 4711)
+    o.train_step(real, ez, er, ec, 60)                                       # non-trivial BatchNorm running statistics
+    sync_from_oracle(o, e, g, d, tr)
+    gen = torch.Generator().manual_seed(99)
+    noises = [(torch.randn(b.shape, generator=gen), torch.randn(b.shape[0], 100, generator=gen)) for b in ref_batches]
+    want = R.validation_epoch(o, ref_batches, [(0.05 * n, z) for n, z in noises])
+    got = V.validation_epoch(e, g, vl, noise_fn=lambda i, img: (noises[i][0].to(DEV), noises[i][1].to(DEV)))
+    assert not e.training and not g.training and d.training                  # :147-148 leaves the discriminator alone
+    assert got["samples"] == want["samples"] == 5 and got["batches"] == 3
+    assert abs(got["val_loss"] - want["val_loss"]) <= 1e-4 * abs(want["val_loss"])
+    assert abs(got["ssim"] - want["ssim"]) < 1e-4 and abs(got["psnr"] - want["psnr"]) < 1e-3
+    # device-generated noise: finite, reproducible per seed
+    torch.cuda.manual_seed(7)
+    a = V.validation_epoch(e, g, vl)
+    torch.cuda.manual_seed(7)
+    b = V.validation_epoch(e, g, vl)
+    assert a == b and all(np.isfinite(v) for v in a.values())

@@ -63,8 +63,9 @@ def _single_process(S, GB, steps, lr):
         for k, v in net.state_dict().items():
             if "running" in k or "num_batches" in k:
                 bufs[f"buf_{name}.{k}"] = v.cpu().numpy()
-    return dict(losses=torch.stack(losses).cpu().numpy(), grad_E=tr.opt_E.flat_g.cpu().numpy(),
-                grad_G=tr.opt_G.flat_g.cpu().numpy(), **bufs)
+    return dict(losses=torch.stack(losses).cpu().numpy(),
+                grad_E=torch.cat([p.grad.flatten() for p in e.parameters()]).cpu().numpy(),
+                grad_G=torch.cat([p.grad.flatten() for p in g.parameters()]).cpu().numpy(), **bufs)
 
 
 def _maxrel(a, b):

@@ -222,6 +222,55 @@ def test_layout_noise_tanh(ops, dtype):
                                atol=1e-2 if dtype else 1e-6)
 
 
+def test_in_kernel_noise_equals_materialised_draws_and_is_standard_normal(ops):
+    """vg_*_rng (the three randn_like draws of vaegan_code.py:77,91,92 generated inside the consuming kernels) against
+    the same kernels fed with vg_randn's materialisation of the same (seed, iteration, draw): bitwise.  Plus the
+    generator itself: moments of N(0,1), distinct draws / iterations, reproducibility per seed."""
+    ns = ops.NoiseStream(DEV, 1234)
+    ns.advance()
+    B, C, H, Ld = 4, 3, 16, 100
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(B, C, H, H, generator=g).to(DEV)
+    for dtype in (G.F32, G.BF16):
+        CP = G.padc(C, dtype)
+        e1 = ns.randn((B, C, H, H), 1)
+        assert torch.equal(ops.nchw_to_nhwc(x, CP, dtype, eps=ns.draw(1), sigma=0.05),
+                           ops.nchw_to_nhwc(x, CP, dtype, eps=e1, sigma=0.05))
+        pre = ops.nchw_to_nhwc(x, CP, dtype)
+        oa, ob = torch.empty_like(pre), torch.empty_like(pre)
+        ya = ops.nhwc_tanh_to_nchw_noisy(pre, C, ns.draw(2), 0.05, oa, dtype)
+        yb = ops.nhwc_tanh_to_nchw_noisy(pre, C, ns.randn((B, C, H, H), 2), 0.05, ob, dtype)
+        assert torch.equal(ya, yb) and torch.equal(oa, ob)
+    mulv = (torch.randn(B, 2 * Ld, generator=g) * 3).to(DEV)
+    ez = ns.randn((B, Ld), 0)
+    za, la = ops.reparam_forward(mulv, ns.draw(0), Ld, Ld, G.F32)
+    zb, lb = ops.reparam_forward(mulv, ez, Ld, Ld, G.F32)
+    assert torch.equal(za, zb) and torch.equal(la, lb)
+    dz = torch.randn(B, 1, 1, Ld, generator=g).to(DEV)
+    assert torch.equal(ops.reparam_kl_backward(mulv, la, ns.draw(0), dz, 0.01, Ld, G.F32),      # backward regenerates
+                       ops.reparam_kl_backward(mulv, la, ez, dz, 0.01, Ld, G.F32))               # the forward's eps
+    # the generator
+    big = ns.randn((1 << 20,), 5).double().cpu()
+    assert abs(float(big.mean())) < 4e-3 and abs(float(big.var()) - 1) < 6e-3
+    assert abs(float((big ** 4).mean()) - 3) < 0.05 and abs(float((big ** 3).mean())) < 0.02   # kurtosis, skew of N(0,1)
+    assert float(big.abs().max()) < 7 and bool(torch.isfinite(big).all())
+    lag = float((big[:-1] * big[1:]).mean())
+    assert abs(lag) < 4e-3                                                  # neighbouring counters are uncorrelated
+    other = ns.randn((1 << 20,), 6).double().cpu()
+    assert abs(float((big * other).mean())) < 4e-3                         # draws are independent streams
+    again = ns.randn((1 << 20,), 5).double().cpu()
+    assert torch.equal(big, again)                                          # same iteration: same numbers
+    ns.advance()
+    nxt = ns.randn((1 << 20,), 5).double().cpu()
+    assert not torch.equal(big, nxt) and abs(float((big * nxt).mean())) < 4e-3      # next iteration: fresh noise
+    ns2 = ops.NoiseStream(DEV, 1234)
+    ns2.advance()
+    assert torch.equal(ns2.randn((1 << 20,), 5).double().cpu(), big)        # reproducible per seed
+    ns3 = ops.NoiseStream(DEV, 1235)
+    ns3.advance()
+    assert not torch.equal(ns3.randn((1 << 20,), 5).double().cpu(), big)
+
+
 def test_reparam_kl_forward_backward(ops):
     """vaegan_code.py:75-77,114 incl. the clamp's gradient mask."""
     B, Ld = 6, 100

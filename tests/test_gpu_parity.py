@@ -115,6 +115,55 @@ def test_generator_discriminator_forward_kat_vs_reference_golden(golden_dir):
     np.testing.assert_allclose(p2.cpu().numpy(), gold["D256.eval.out"], rtol=1e-4, atol=1e-6)
 
 
+
+# State after the FIRST iteration against the reference-generated checksums (steps_S256_*.npz "after1.*": sum, abs-sum,
+# sum of squares of every parameter / BatchNorm buffer / Adam moment after vaegan_code.py:65-135 ran once from the
+# seed-42 state).  exp_avg after one Adam step is (1-beta1)*grad, exp_avg_sq is (1-beta2)*grad^2, so the moment
+# checksums pin the whole backward pass of iteration 1 (D: its two updates) against the reference.  Tolerances:
+#   * Adam moments, per tensor: abs-sum and sum of squares within MOMENT_TOL relative; the plain sum (which cancels)
+#     within MOMENT_TOL of the abs-sum.  Tensors whose reference gradient is rounding noise (a conv bias in front of
+#     BatchNorm: exactly zero in exact arithmetic) are skipped -- any two fp32 implementations disagree there.
+#   * BatchNorm running statistics: same form, BUFFER_TOL.
+#   * parameters: one Adam(t=1) step moves every weight by lr*sign(g) (eps aside), so two implementations differ by
+#     2*lr on every weight whose gradient sign differs; the checksum of the parameters must agree within
+#     2*lr*n*FLIP_FRAC, i.e. at most FLIP_FRAC of a tensor's weights may have moved the other way (D takes two steps).
+MOMENT_TOL, BUFFER_TOL, FLIP_FRAC = 2e-2, 2e-3, 0.05
+
+
+def check_state_after_first_iteration(gold, e, g, d, tr, lr=2e-4):
+    worst = {"moment": 0.0, "buffer": 0.0, "param_flip": 0.0}
+    for name, m, opt in (("E", e, tr.opt_E), ("G", g, tr.opt_G), ("D", d, tr.opt_D)):
+        steps = 2 if name == "D" else 1
+        sd = m.state_dict()
+        for k, v in sd.items():
+            ref = gold[f"after1.{name}.{k}#stats"]
+            if k.endswith("num_batches_tracked"):
+                assert int(v) == int(gold[f"after1.{name}.{k}#samp"][0]), k
+                continue
+            got, _ = tstats(v.float())
+            if k.endswith("running_mean") or k.endswith("running_var"):
+                err = max(abs(got[1] - ref[1]) / ref[1], abs(got[2] - ref[2]) / ref[2], abs(got[0] - ref[0]) / ref[1])
+                worst["buffer"] = max(worst["buffer"], err)
+                assert err <= BUFFER_TOL, f"after iteration 1: {name}.{k} checksum differs by {err:.2e}"
+            elif not (name == "E" and k.endswith("conv.bias")):
+                flips = abs(got[0] - ref[0]) / (2 * lr * steps * v.numel())
+                worst["param_flip"] = max(worst["param_flip"], flips)
+                assert flips <= FLIP_FRAC, f"after iteration 1: {name}.{k} parameter checksum off by {flips:.3f} x 2*lr*n"
+        hsd = opt.state_dict()["state"]
+        for i in range(len(hsd)):
+            for mom in ("exp_avg", "exp_avg_sq"):
+                ref = gold[f"after1.adam.{name}.{i}.{mom}#stats"]
+                got, _ = tstats(hsd[i][mom])
+                n = hsd[i][mom].numel()
+                if mom == "exp_avg" and ref[1] / n < 1e-9:
+                    continue                                            # rounding-noise gradient (see above)
+                if mom == "exp_avg_sq" and ref[1] / n < 1e-18:
+                    continue
+                err = max(abs(got[1] - ref[1]) / ref[1], abs(got[2] - ref[2]) / ref[2], abs(got[0] - ref[0]) / ref[1])
+                worst["moment"] = max(worst["moment"], err)
+                assert err <= MOMENT_TOL, f"after iteration 1: Adam {name} param {i} {mom} checksum differs by {err:.2e}"
+    print("after-iteration-1 state vs reference checksums, worst:", {k: f"{v:.2e}" for k, v in worst.items()})
+
 # --------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("B,epoch", [(2, 25), (2, 60), (4, 0)])
 def test_three_training_steps_vs_reference_golden_S256(golden_dir, B, epoch):
@@ -131,6 +180,8 @@ def test_three_training_steps_vs_reference_golden_S256(golden_dir, B, epoch):
             ref = float(gold["losses"][step][j])
             tol = FIRST_STEP_TOL[n] if step == 0 else later_step_tol(ref, r64[n])
             assert rel(got[n], ref) <= tol, f"step {step} {n}: hip {got[n]} reference {ref} (tol {tol:.1e})"
+        if step == 0:
+            check_state_after_first_iteration(gold, e, g, d, tr)
     assert float(tr.opt_D.state_dev[0]) == 6 and float(tr.opt_E.state_dev[0]) == 3
     for name, m in (("E", e), ("G", g), ("D", d)):
         sd = m.state_dict()
@@ -286,6 +337,43 @@ def test_bf16_engine_tracks_fp32_oracle():
         assert p.dtype == torch.float32 and bool(torch.isfinite(p).all())
 
 
+@pytest.mark.parametrize("S,B,dtype", [(64, 128, "fp32"), (64, 128, "bf16"), (128, 64, "bf16")])
+def test_benchmarked_configurations_replayed_graph_vs_oracle(S, B, dtype):
+    """The configurations bench.py / BASELINE.json time -- C2 (S=64, B=128, bf16, hipGraph replay) with its fp32
+    parity twin, and the per-GPU shard of C3 (S=128, B=64, bf16) -- end to end against the live CPU oracle: the first
+    iteration from the seed-42 state, executed by the REPLAYED graph (the tile picker chooses other kernels at these
+    batch sizes than at the small parity batches: 256x128 / 128x128 patch tiles, grouped 2B-row D passes)."""
+    e, g, d, tr = build(S, dtype=dtype)
+    o = R.RefVAEGAN(img_size=S, seed=42)
+    real, ez, er, ec = make_inputs(B, S, 1234)
+    dev_in = [t.to(DEV) for t in (real, ez, er, ec)]
+    start = tr.state_dict()
+    start = {k: (v if not isinstance(v, dict) else _deep_clone(v)) for k, v in start.items()}
+    eager = tr.loss_dict(tr.train_step_graphed(dev_in[0], 60, *dev_in[1:]).clone(), 60)     # eager warm-up call
+    tr.train_step_graphed(dev_in[0], 60, *dev_in[1:])                                        # capture + first replay
+    assert tr._graph is not None and len(tr._graph[1]) == 1
+    tr.load_state_dict(start)                                                                # back to the seed-42 state
+    graph = tr._graph
+    got = tr.loss_dict(tr.train_step_graphed(dev_in[0], 60, *dev_in[1:]).clone(), 60)        # pure replay
+    assert tr._graph is graph, "the restored state must replay the captured graph, not re-capture"
+    ref = o.train_step(real, ez, er, ec, 60)
+    for n in V.LOSS_NAMES + ("total",):
+        tol = FIRST_STEP_TOL[n] if dtype == "fp32" else 3e-2          # bf16: stated tolerance of the bf16 path
+        assert rel(got[n], ref[n]) <= tol, f"S={S} B={B} {dtype} replay {n}: hip {got[n]} oracle {ref[n]} (tol {tol:.0e})"
+        assert got[n] == eager[n], f"replayed graph differs from the eager iteration in {n}: {got[n]} vs {eager[n]}"
+    print(f"S={S} B={B} {dtype}:", {n: f"{rel(got[n], ref[n]):.1e}" for n in V.LOSS_NAMES})
+
+
+def _deep_clone(x):
+    if isinstance(x, torch.Tensor):
+        return x.detach().clone()
+    if isinstance(x, dict):
+        return {k: _deep_clone(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return type(x)(_deep_clone(v) for v in x)
+    return x
+
+
 def test_grouped_discriminator_pass_equals_separate_passes():
     """One grouped 2B-row pass per D iteration (per-group BatchNorm statistics) vs the reference's two calls."""
     outs = []
@@ -308,8 +396,8 @@ def test_grouped_discriminator_pass_equals_separate_passes():
 
 
 class _LocalReducer:
-    """world_size-1 stand-in with the GradReducer surface: lets the single GPU exercise the SEGMENTED graph path
-    (collectives between hipGraph segments) and records how the trainer drives it."""
+    """world_size-1 stand-in with the whole-buffer GradReducer surface: lets the single GPU exercise the SEGMENTED
+    graph path (collectives between hipGraph segments) and records how the trainer drives it."""
 
     def __init__(self):
         self.calls = []
@@ -323,6 +411,42 @@ class _LocalReducer:
 
     def wait(self, opt):
         self.calls.append(("wait", id(opt)))
+
+
+class _LocalBucketReducer(_LocalReducer):
+    """Same, with the BUCKETED surface (plan / launch_ready / drain / outstanding) of ddp.GradReducer: buckets are
+    planned by the real ddp.plan_buckets, 'launching' one is an eager op on its slice of the gradient buffer."""
+
+    def __init__(self, bucket_bytes):
+        super().__init__()
+        self.bucket_bytes, self.plans, self.pending = bucket_bytes, {}, 0
+
+    def plan(self, opt, ready):
+        import importlib
+        ddp = importlib.import_module("vae-gan-based-model-for-image-generation-and-denoising_amd.ddp")
+        self.plans[id(opt)] = ddp.plan_buckets(opt.offsets, [p.numel() for p in opt.params], ready,
+                                               opt.flat_g.numel(), self.bucket_bytes)
+        return self.plans[id(opt)]
+
+    def launch_ready(self, opt, event):
+        n = 0
+        for lo, hi, ev in self.plans[id(opt)]:
+            if ev == event:
+                opt.flat_g[lo:hi].mul_(1.0)
+                self.calls.append(("bucket", id(opt), lo, hi))
+                self.pending += 1
+                n += 1
+        return n
+
+    def wait(self, opt):
+        super().wait(opt)
+        self.pending = 0
+
+    def drain(self):
+        self.pending = 0
+
+    def outstanding(self):
+        return self.pending
 
 
 def test_segmented_graph_replay_with_reducer_is_bitwise_identical_to_eager():
@@ -342,9 +466,103 @@ def test_segmented_graph_replay_with_reducer_is_bitwise_identical_to_eager():
     for a, b in zip(res[0][:4], res[1][:4]):
         assert torch.equal(a, b)
     assert res[0][4] == res[1][4] == 8.0
-    per_step = ["reduce", "reduce", "async", "reduce", "wait"]               # D, D, G (async), E, wait(G)
+    per_step = ["reduce", "wait", "reduce", "wait", "async", "reduce", "wait", "wait"]   # D, D, G (async), E + wait(E), wait(G)
     assert calls[0] == per_step * 4
     assert calls[1] == per_step * 4                  # eager warm-up + 3 replays (capture itself runs no collective)
+
+
+def test_bucketed_reduction_cuts_the_graph_at_every_bucket_and_equals_eager():
+    """ddp buckets (reverse layer order) under graph replay: one hipGraph segment boundary per bucket launch, every
+    bucket of every optimizer launched exactly once per use and before that optimizer's step, results bit-identical
+    to the eager iteration.  Small bucket size so that each network has several buckets."""
+    res, calls, plans = [], [], []
+    for graphed in (False, True):
+        e, g, d, tr = build(64)
+        tr.reducer = _LocalBucketReducer(bucket_bytes=1 << 20)
+        fn = tr.train_step_graphed if graphed else tr.train_step
+        for step in range(4):
+            real, ez, er, ec = (t.to(DEV) for t in make_inputs(4, 64, 7064 + step))
+            l = fn(real, 60, ez, er, ec)
+        res.append((l[:5].cpu().clone(), tr.opt_E.flat_p.cpu().clone(), tr.opt_G.flat_p.cpu().clone(),
+                    tr.opt_D.flat_p.cpu().clone()))
+        calls.append(list(tr.reducer.calls))
+        plans.append({k: list(v) for k, v in tr.reducer.plans.items()})
+        if graphed:
+            nb = {o: len(plans[-1][id(o)]) for o in (tr.opt_E, tr.opt_G, tr.opt_D)}
+            cuts_in_backward = lambda o: len({ev for _, _, ev in plans[-1][id(o)] if ev > 0})
+            expect_cuts = 2 * (cuts_in_backward(tr.opt_D) + 1) + (cuts_in_backward(tr.opt_G) + 1) + (cuts_in_backward(tr.opt_E) + 1)
+            assert len(tr._graph[2]) == expect_cuts and len(tr._graph[1]) == expect_cuts + 1
+            assert nb[tr.opt_G] >= 3 and nb[tr.opt_D] >= 2
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
+    assert [c[0] for c in calls[0]] == [c[0] for c in calls[1]]              # same hand-off sequence eager / replayed
+    # per iteration: every bucket of D twice (two D updates), of G and E once
+    per_iter = len(calls[1]) // 4
+    one = [c for c in calls[1][:per_iter] if c[0] == "bucket"]
+    for o, uses in ((tr.opt_D, 2), (tr.opt_G, 1), (tr.opt_E, 1)):
+        got = sorted((c[2], c[3]) for c in one if c[1] == id(o))
+        want = sorted([(lo, hi) for lo, hi, _ in plans[1][id(o)]] * uses)
+        assert got == want
+
+
+def test_graph_capture_is_refused_while_collectives_are_outstanding():
+    """Structural guard for the abort recorded in round 1 (c10d's watchdog polling an unfinished collective with
+    hipEventQuery next to a capturing stream): before capture_begin the trainer drains the reducer and refuses to
+    capture if it still reports outstanding work -- instead of relying on it having happened to be idle."""
+    e, g, d, tr = build(64)
+
+    class _Stuck(_LocalBucketReducer):
+        def drain(self):                            # a reducer whose work cannot be retired
+            pass
+
+        def wait(self, opt):
+            _LocalReducer.wait(self, opt)
+
+    tr.reducer = _Stuck(bucket_bytes=1 << 20)
+    real, ez, er, ec = (t.to(DEV) for t in make_inputs(4, 64, 7064))
+    tr.train_step_graphed(real, 60, ez, er, ec)                  # eager warm-up: leaves `pending` > 0 (never retired)
+    assert tr.reducer.outstanding() > 0
+    before = tr.opt_G.flat_p.clone()
+    with pytest.raises(RuntimeError, match="capture refused"):
+        tr.train_step_graphed(real, 60, ez, er, ec)
+    assert torch.equal(before, tr.opt_G.flat_p) and tr._graph is None       # nothing ran, nothing half-captured
+    tr.reducer.pending = 0                                        # once idle, the same call captures and replays
+    tr.train_step_graphed(real, 60, ez, er, ec)
+    assert tr._graph is not None
+
+
+def test_replayed_graph_survives_workspace_growth_by_later_eager_work():
+    """A captured graph holds raw pointers into the shared scratch buffers (BatchNorm slabs, split-K / wgrad slabs).
+    A later, LARGER eager call grows those buffers; the superseded ones must stay alive (ops._Workspace retires them)
+    or the graph would replay into freed memory.  Capture at B=8, run another trainer eagerly at B=32 (and let the
+    allocator reuse whatever was freed), replay: must equal an undisturbed run bit for bit."""
+    import gc
+    ins = [tuple(t.to(DEV) for t in make_inputs(8, 64, 7064 + i)) for i in range(4)]
+
+    import importlib
+    ops_mod = importlib.import_module("vae-gan-based-model-for-image-generation-and-denoising_amd.ops")
+
+    def run(disturb):
+        ops_mod.WS.bufs.clear()                     # scratch sized by THIS run's B=8 capture, whatever ran before
+        e, g, d, tr = build(64)
+        out = []
+        for i in range(4):
+            if disturb and i == 2:
+                before = {k: v.data_ptr() for k, v in ops_mod.WS.bufs.items()}
+                e2, g2, d2, tr2 = build(64)
+                big = tuple(t.to(DEV) for t in make_inputs(32, 64, 99))
+                tr2.train_step(big[0], 60, *big[1:])
+                assert any(ops_mod.WS.bufs[k].data_ptr() != p for k, p in before.items()), "no workspace grew"
+                del e2, g2, d2, tr2, big
+                gc.collect()
+                junk = [torch.full((1 << 20,), float("nan"), device=DEV) for _ in range(64)]   # poison recycled blocks
+                del junk
+            out.append(tr.train_step_graphed(ins[i][0], 60, *ins[i][1:])[:5].clone())
+        return torch.stack(out).cpu(), tr.opt_G.flat_p.cpu().clone(), tr.opt_D.flat_p.cpu().clone()
+
+    ref, dis = run(False), run(True)
+    for a, b in zip(ref, dis):
+        assert torch.equal(a, b)
 
 
 def test_graph_replay_is_bitwise_identical_to_eager():

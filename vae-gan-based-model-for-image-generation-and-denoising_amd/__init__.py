@@ -9,7 +9,7 @@ vaegan_code.py:42-44), ``BCELoss`` / ``MSELoss`` (vaegan_code.py:46-47), ``confi
 from . import data  # noqa: F401
 from . import geometry  # noqa: F401
 from .ddp import GradReducer
-from .denoise import denoise_eval
+from .denoise import denoise_eval, validation_epoch
 from .losses import BCELoss, MSELoss
 from .nets import ConvBlock, Discriminator, Encoder, Generator, weights_init
 from .optim import Adam
@@ -18,4 +18,4 @@ from .trainer import LOSS_NAMES, VAEGANTrainer
 from .utils import configure_seed
 
 __all__ = ["ConvBlock", "Encoder", "Generator", "Discriminator", "weights_init", "Adam", "BCELoss", "MSELoss",
-           "VAEGANTrainer", "LOSS_NAMES", "configure_seed", "geometry", "denoise_eval", "GradReducer", "data", "VAETrainer", "DCGANTrainer", "WGANTrainer"]
+           "VAEGANTrainer", "LOSS_NAMES", "configure_seed", "geometry", "denoise_eval", "validation_epoch", "GradReducer", "data", "VAETrainer", "DCGANTrainer", "WGANTrainer"]

@@ -15,7 +15,7 @@ import torch  # noqa: F401  (must be loaded before the HIP library, see module d
 VG_F32, VG_BF16 = 0, 1
 VG_ACT_NONE, VG_ACT_RELU, VG_ACT_LRELU = 0, 1, 2
 VG_MAX_PHASE = 4
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _ERR = {-1: "VG_EINVAL (bad shape/size/flag)", -2: "VG_EALIGN (16-byte contract violated)",
         -3: "VG_ENOSUP (unsupported configuration)"}
@@ -109,6 +109,13 @@ SIGNATURES = {
     "vg_ssim": (c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _I, _P]),
     "vg_axpy": (c_int, [_P, _P, _F, _P, _L, _P]),
     "vg_adam_step": (c_int, [_P, _P, _P, _P, _L, _D, _D, _D, _D, _F, _P, _P]),
+    "vg_rng_advance": (c_int, [_P, _P]),
+    "vg_randn": (c_int, [_P, _L, _P, _I, _P]),
+    "vg_nchw_to_nhwc_rng": (c_int, [_P, _P, _I, _F, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "vg_nhwc_tanh_to_nchw_noisy_rng": (c_int, [_P, _P, _P, _I, _F, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "vg_reparam_forward_rng": (c_int, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "vg_reparam_kl_backward_rng": (c_int, [_P, _P, _P, _I, _P, _F, _P, _I, _I, _I, _I, _I, _P]),
+    "vg_memset_zero": (c_int, [_P, _L, _P]),
 }
 
 LIB_PATH = os.environ.get("VG_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libvaegan_hip.so")

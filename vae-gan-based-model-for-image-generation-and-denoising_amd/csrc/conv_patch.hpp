@@ -129,13 +129,21 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 2 : 1) void ggp_kernel(const vg
             const int iy = (gy0 + pr) * d.SY + cy;
             const int ix = pc * d.SX + cx;
             const bool ok = pp < g.NPP && b < d.B && (unsigned)iy < (unsigned)d.IH && (unsigned)ix < (unsigned)d.IW;
+#ifdef VG_ABL_A_L2          // timing-only build: every patch read hits a 256 KB window (L2-resident)
+            a_cur[r] = ok ? Xb + (((uint32_t)((b * d.IH + iy) * d.IW + ix) * pix_bytes) & 0x3ffc0u) + (uint32_t)q * 16u : Zp;
+            a_live |= 0u;
+#else
             a_cur[r] = ok ? Xb + ((uint32_t)((b * d.IH + iy) * d.IW + ix) * pix_bytes + (uint32_t)q * 16u) : Zp;
             a_live |= ok ? (1u << r) : 0u;
+#endif
         }
     };
     // issue-side cursors
     int pj_cl = 0, pj_c = 0;                                    // (class, chunk) of the NEXT patch to fetch
     auto issue_patch_round = [&](int buf, int r) {              // r is a compile-time constant at every call site
+#ifdef VG_ABL_NO_A
+        return;
+#endif
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a_cur[r],
                                          (__attribute__((address_space(3))) void*)(pbuf + buf * GP_PBUF + (NT * r + 64 * wave_u) * 16),
                                          16, 0, 0);
@@ -146,6 +154,9 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 2 : 1) void ggp_kernel(const vg
     };
     int bs_cl = 0, bs_c = 0, bs_k = 0;                          // (class, chunk, tap-in-class) of the NEXT weight stage
     auto issue_b = [&](int buf) {                                // the TPS taps of one stage
+#ifdef VG_ABL_NO_B
+        return;
+#endif
 #pragma unroll
         for (int tp = 0; tp < TPS; ++tp) {
             const int py = bs_cl / g.ncx, px = bs_cl - py * g.ncx;
@@ -185,6 +196,9 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 2 : 1) void ggp_kernel(const vg
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     auto compute = [&](int pb, int bb, int k) {
+#ifdef VG_ABLATE_COMPUTE
+        return;
+#endif
         const int a = k >> 1, b = k & 1;
         const int shy = a ? sh_y1 : 1 - sh_y1, shx = b ? sh_x1 : 1 - sh_x1;
         const int tapoff = shy * g.PW + shx;
@@ -296,6 +310,13 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 2 : 1) void ggp_kernel(const vg
     }
 
     // ---------------- epilogue (as gg_kernel<bf16, 128, 128>) ----------------
+#ifdef VG_ABL_NO_EPI
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(acc[i][j]));
+    return;
+#endif
     typedef ElemT<VG_BF16> E;
     constexpr int ESZ = 2;
     const bool flat = (d.nphase == 1 && d.OSY == 1 && d.OSX == 1 && d.GH == d.OH && d.GW == d.OW);

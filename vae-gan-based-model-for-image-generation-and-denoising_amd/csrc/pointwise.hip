@@ -5,9 +5,49 @@
 
 namespace {
 
+// ---- in-kernel N(0,1) draws: the three randn_like of an iteration (vaegan_code.py:77,91,92) -------------------
+// Counter-based Philox4x32-10 (Salmon et al., SC'11): key = 64-bit seed, counter = (element index, draw id, step).
+// state[0] = seed, state[1] = iteration counter, both in device memory: a replayed hipGraph reads the counter the
+// one-thread vg_rng_advance kernel bumped at the top of the iteration, so every replay draws fresh noise, and the
+// backward of the reparameterisation regenerates exactly the eps its forward used.  Box-Muller on two of the four
+// output words.  A NoiseSrc with eps != NULL reads injected noise instead (parity runs).
+struct NoiseSrc {
+    const float* eps;
+    const unsigned long long* rng;
+    uint32_t draw;
+};
+
+__device__ __forceinline__ float philox_randn(unsigned long long seed, unsigned long long step, uint32_t draw,
+                                              unsigned long long idx) {
+    uint32_t c0 = (uint32_t)idx, c1 = (uint32_t)(idx >> 32), c2 = (uint32_t)step, c3 = ((uint32_t)(step >> 32) << 8) | draw;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    const float u1 = ((float)c0 + 0.5f) * 2.3283064365386963e-10f;            // (0, 1]: 2^-32 * (x + 0.5), never 0
+    const float u2 = ((float)c1 + 0.5f) * 2.3283064365386963e-10f;
+    return sqrtf(-2.f * __logf(fmaxf(u1, 1e-30f))) * __cosf(6.283185307179586f * u2);
+}
+
+__device__ __forceinline__ float noise_at(const NoiseSrc& n, int64_t idx) {
+    if (n.eps) return n.eps[idx];
+    return philox_randn(n.rng[0], n.rng[1], n.draw, (unsigned long long)idx);
+}
+
+__global__ void rng_advance_kernel(unsigned long long* state) { state[1] += 1ull; }
+
+__global__ __launch_bounds__(256) void randn_fill_kernel(float* __restrict__ out, int64_t n, NoiseSrc src) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = noise_at(src, i);
+}
+
 // ---- NCHW f32  <->  NHWC (dtype, channels padded to CP) ----------------------------------------
 template <int DT>
-__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, const float* __restrict__ eps,
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, const NoiseSrc eps,
                                                            float sigma, void* __restrict__ y, int64_t npix, int C,
                                                            int HW, int CP, float lo, float hi, float* __restrict__ y_nchw) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
@@ -22,7 +62,7 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
                 if (c < C) {
                     const int64_t src = (b * C + c) * HW + hw;
                     float t = x[src];
-                    if (eps) t = t + sigma * eps[src];
+                    if (eps.eps || eps.rng) t = t + sigma * noise_at(eps, src);
                     t = fminf(fmaxf(t, lo), hi);
                     if (y_nchw) y_nchw[src] = t;
                     v[k] = t;
@@ -76,7 +116,7 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const void* __restric
 // recon_noisy = recon + sigma * eps in the Discriminator's NHWC input layout.
 template <int DT>
 __global__ __launch_bounds__(256) void nhwc_tanh_noisy_kernel(const void* __restrict__ x, float* __restrict__ y,
-                                                              const float* __restrict__ eps, float sigma,
+                                                              const NoiseSrc eps, float sigma,
                                                               void* __restrict__ yn, int64_t npix, int C, int HW,
                                                               int CP) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
@@ -93,7 +133,7 @@ __global__ __launch_bounds__(256) void nhwc_tanh_noisy_kernel(const void* __rest
                     const int64_t dst = (b * C + c) * HW + hw;
                     const float t = tanhf(v[k]);
                     y[dst] = t;
-                    o[k] = t + sigma * eps[dst];
+                    o[k] = t + sigma * noise_at(eps, dst);
                 }
             }
             store4<DT>(yn, i * CP + c0, float4{o[0], o[1], o[2], o[3]});
@@ -131,7 +171,7 @@ __global__ __launch_bounds__(256) void nchw_grad_to_nhwc_kernel(const float* __r
 
 // ---- reparameterisation / KL ----------------------------------------------------------------------
 template <int DT>
-__global__ void reparam_fwd_kernel(const void* __restrict__ mulv, const float* __restrict__ eps, void* __restrict__ z,
+__global__ void reparam_fwd_kernel(const void* __restrict__ mulv, const NoiseSrc eps, void* __restrict__ z,
                                    float* __restrict__ lvc, int B, int L, int MP, int ZP) {
     const int total = B * ZP;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
@@ -142,7 +182,7 @@ __global__ void reparam_fwd_kernel(const void* __restrict__ mulv, const float* _
             float lv = load1<DT>(mulv, (int64_t)b * MP + L + j);
             lv = fminf(fmaxf(lv, -10.f), 10.f);
             lvc[b * L + j] = lv;
-            zv = mu + expf(0.5f * lv) * eps[b * L + j];
+            zv = mu + expf(0.5f * lv) * noise_at(eps, b * L + j);
         }
         store1<DT>(z, i, zv);
     }
@@ -186,7 +226,7 @@ __global__ __launch_bounds__(1024) void kl_kernel(const void* __restrict__ mulv,
 
 template <int DT>
 __global__ void reparam_kl_bwd_kernel(const void* __restrict__ mulv, const float* __restrict__ lvc,
-                                      const float* __restrict__ eps, const void* __restrict__ dz, float kl_scale,
+                                      const NoiseSrc eps, const void* __restrict__ dz, float kl_scale,
                                       void* __restrict__ dmulv, int B, int L, int MP, int ZP) {
     const int total = B * MP;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
@@ -201,7 +241,7 @@ __global__ void reparam_kl_bwd_kernel(const void* __restrict__ mulv, const float
             if (raw >= -10.f && raw <= 10.f) {
                 const float lv = lvc[b * L + jj];
                 const float d = load1<DT>(dz, (int64_t)b * ZP + jj);
-                g = d * (0.5f * expf(0.5f * lv) * eps[b * L + jj]) + kl_scale * 0.5f * (expf(lv) - 1.f);
+                g = d * (0.5f * expf(0.5f * lv) * noise_at(eps, b * L + jj)) + kl_scale * 0.5f * (expf(lv) - 1.f);
             }
         }
         store1<DT>(dmulv, i, g);
@@ -448,9 +488,38 @@ extern "C" int vg_nchw_to_nhwc(const float* x, const float* eps, float sigma, vo
     CHECK_DT();
     VG_CHECK_ARG(x && y && B > 0 && C > 0 && H > 0 && W > 0 && CP >= C && CP % 4 == 0, VG_EINVAL);
     const int64_t npix = (int64_t)B * H * W;
-    DISPATCH_DT(nchw_to_nhwc_kernel, dim3(blocks_for(npix)), dim3(256), vg_stream(stream), x, eps, sigma, y, npix, C,
+    DISPATCH_DT(nchw_to_nhwc_kernel, dim3(blocks_for(npix)), dim3(256), vg_stream(stream), x, (NoiseSrc{eps, nullptr, 0u}), sigma, y, npix, C,
                 H * W, CP, -3.0e38f, 3.0e38f, (float*)nullptr);
     return VG_LAUNCH_RC();
+}
+
+extern "C" int vg_nchw_to_nhwc_rng(const float* x, const uint64_t* rng, int draw, float sigma, void* y, int B, int C,
+                                   int H, int W, int CP, int dtype, void* stream) {
+    CHECK_DT();
+    VG_CHECK_ARG(x && rng && y && draw >= 0 && draw < 256 && B > 0 && C > 0 && H > 0 && W > 0 && CP >= C && CP % 4 == 0, VG_EINVAL);
+    const int64_t npix = (int64_t)B * H * W;
+    DISPATCH_DT(nchw_to_nhwc_kernel, dim3(blocks_for(npix)), dim3(256), vg_stream(stream), x,
+                (NoiseSrc{nullptr, (const unsigned long long*)rng, (uint32_t)draw}), sigma, y, npix, C, H * W, CP, -3.0e38f, 3.0e38f,
+                (float*)nullptr);
+    return VG_LAUNCH_RC();
+}
+
+extern "C" int vg_rng_advance(uint64_t* rng, void* stream) {
+    VG_CHECK_ARG(rng != nullptr, VG_EINVAL);
+    hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, vg_stream(stream), (unsigned long long*)rng);
+    return VG_LAUNCH_RC();
+}
+
+extern "C" int vg_randn(float* out, int64_t n, const uint64_t* rng, int draw, void* stream) {
+    VG_CHECK_ARG(out && rng && n > 0 && draw >= 0 && draw < 256, VG_EINVAL);
+    hipLaunchKernelGGL(randn_fill_kernel, dim3(blocks_for(n)), dim3(256), 0, vg_stream(stream), out, n,
+                       NoiseSrc{nullptr, (const unsigned long long*)rng, (uint32_t)draw});
+    return VG_LAUNCH_RC();
+}
+
+extern "C" int vg_memset_zero(void* p, int64_t nbytes, void* stream) {
+    VG_CHECK_ARG(p && nbytes > 0, VG_EINVAL);
+    return (int)hipMemsetAsync(p, 0, (size_t)nbytes, vg_stream(stream));
 }
 
 extern "C" int vg_gather_normalize_u8(const uint8_t* images, int64_t N, const int64_t* idx, int B, int C, int H, int W,
@@ -467,7 +536,7 @@ extern "C" int vg_noisy_clamp_to_nhwc(const float* x, const float* eps, float si
     CHECK_DT();
     VG_CHECK_ARG(x && eps && y && B > 0 && C > 0 && H > 0 && W > 0 && CP >= C && CP % 4 == 0 && lo <= hi, VG_EINVAL);
     const int64_t npix = (int64_t)B * H * W;
-    DISPATCH_DT(nchw_to_nhwc_kernel, dim3(blocks_for(npix)), dim3(256), vg_stream(stream), x, eps, sigma, y, npix, C,
+    DISPATCH_DT(nchw_to_nhwc_kernel, dim3(blocks_for(npix)), dim3(256), vg_stream(stream), x, (NoiseSrc{eps, nullptr, 0u}), sigma, y, npix, C,
                 H * W, CP, lo, hi, y_nchw);
     return VG_LAUNCH_RC();
 }
@@ -488,8 +557,20 @@ extern "C" int vg_nhwc_tanh_to_nchw_noisy(const void* x, float* y_nchw, const fl
     VG_CHECK_ARG(x && y_nchw && eps && y_noisy_nhwc && B > 0 && C > 0 && H > 0 && W > 0 && CP >= C && CP % 4 == 0,
                  VG_EINVAL);
     const int64_t npix = (int64_t)B * H * W;
-    DISPATCH_DT(nhwc_tanh_noisy_kernel, dim3(blocks_for(npix)), dim3(256), vg_stream(stream), x, y_nchw, eps, sigma,
+    DISPATCH_DT(nhwc_tanh_noisy_kernel, dim3(blocks_for(npix)), dim3(256), vg_stream(stream), x, y_nchw, (NoiseSrc{eps, nullptr, 0u}), sigma,
                 y_noisy_nhwc, npix, C, H * W, CP);
+    return VG_LAUNCH_RC();
+}
+
+extern "C" int vg_nhwc_tanh_to_nchw_noisy_rng(const void* x, float* y_nchw, const uint64_t* rng, int draw, float sigma,
+                                              void* y_noisy_nhwc, int B, int C, int H, int W, int CP, int dtype,
+                                              void* stream) {
+    CHECK_DT();
+    VG_CHECK_ARG(x && y_nchw && rng && y_noisy_nhwc && draw >= 0 && draw < 256 && B > 0 && C > 0 && H > 0 && W > 0 &&
+                 CP >= C && CP % 4 == 0, VG_EINVAL);
+    const int64_t npix = (int64_t)B * H * W;
+    DISPATCH_DT(nhwc_tanh_noisy_kernel, dim3(blocks_for(npix)), dim3(256), vg_stream(stream), x, y_nchw,
+                (NoiseSrc{nullptr, (const unsigned long long*)rng, (uint32_t)draw}), sigma, y_noisy_nhwc, npix, C, H * W, CP);
     return VG_LAUNCH_RC();
 }
 
@@ -517,8 +598,17 @@ extern "C" int vg_reparam_forward(const void* mulv, const float* eps, void* z, f
                                   int ZP, int dtype, void* stream) {
     CHECK_DT();
     VG_CHECK_ARG(mulv && eps && z && lv_clamped && B > 0 && L > 0 && MP >= 2 * L && ZP >= L, VG_EINVAL);
-    DISPATCH_DT(reparam_fwd_kernel, dim3(blocks_for((int64_t)B * ZP)), dim3(256), vg_stream(stream), mulv, eps, z,
+    DISPATCH_DT(reparam_fwd_kernel, dim3(blocks_for((int64_t)B * ZP)), dim3(256), vg_stream(stream), mulv, (NoiseSrc{eps, nullptr, 0u}), z,
                 lv_clamped, B, L, MP, ZP);
+    return VG_LAUNCH_RC();
+}
+
+extern "C" int vg_reparam_forward_rng(const void* mulv, const uint64_t* rng, int draw, void* z, float* lv_clamped, int B,
+                                      int L, int MP, int ZP, int dtype, void* stream) {
+    CHECK_DT();
+    VG_CHECK_ARG(mulv && rng && z && lv_clamped && draw >= 0 && draw < 256 && B > 0 && L > 0 && MP >= 2 * L && ZP >= L, VG_EINVAL);
+    DISPATCH_DT(reparam_fwd_kernel, dim3(blocks_for((int64_t)B * ZP)), dim3(256), vg_stream(stream), mulv,
+                (NoiseSrc{nullptr, (const unsigned long long*)rng, (uint32_t)draw}), z, lv_clamped, B, L, MP, ZP);
     return VG_LAUNCH_RC();
 }
 
@@ -536,7 +626,18 @@ extern "C" int vg_reparam_kl_backward(const void* mulv, const float* lv_clamped,
     CHECK_DT();
     VG_CHECK_ARG(mulv && lv_clamped && eps && dz && dmulv && B > 0 && L > 0 && MP >= 2 * L && ZP >= L, VG_EINVAL);
     DISPATCH_DT(reparam_kl_bwd_kernel, dim3(blocks_for((int64_t)B * MP)), dim3(256), vg_stream(stream), mulv,
-                lv_clamped, eps, dz, kl_scale, dmulv, B, L, MP, ZP);
+                lv_clamped, (NoiseSrc{eps, nullptr, 0u}), dz, kl_scale, dmulv, B, L, MP, ZP);
+    return VG_LAUNCH_RC();
+}
+
+extern "C" int vg_reparam_kl_backward_rng(const void* mulv, const float* lv_clamped, const uint64_t* rng, int draw,
+                                          const void* dz, float kl_scale, void* dmulv, int B, int L, int MP, int ZP,
+                                          int dtype, void* stream) {
+    CHECK_DT();
+    VG_CHECK_ARG(mulv && lv_clamped && rng && dz && dmulv && draw >= 0 && draw < 256 && B > 0 && L > 0 && MP >= 2 * L &&
+                 ZP >= L, VG_EINVAL);
+    DISPATCH_DT(reparam_kl_bwd_kernel, dim3(blocks_for((int64_t)B * MP)), dim3(256), vg_stream(stream), mulv,
+                lv_clamped, (NoiseSrc{nullptr, (const unsigned long long*)rng, (uint32_t)draw}), dz, kl_scale, dmulv, B, L, MP, ZP);
     return VG_LAUNCH_RC();
 }
 

@@ -368,6 +368,9 @@ __global__ __launch_bounds__(256) void wgrad_bf16_dma_kernel(const vg_wg_desc d,
         }
     };
     auto issue_stage = [&](int buf, int slot, int ms) {
+#ifdef VG_ABL_NO_LOAD
+        return;
+#endif
         unsigned char* sp = smem + buf * WD_STAGE;
         unsigned char* sq = sp + WD_SM * WB_PITCH;
 #pragma unroll
@@ -415,6 +418,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_dma_kernel(const vg_wg_desc d,
         if (s + WD_NBUF < nstage) fill_table((s + WD_NBUF) & 3, m_begin + (s + WD_NBUF) * WD_SM);
         const unsigned char* sp = smem + rb * WD_STAGE;
         const unsigned char* sq = sp + WD_SM * WB_PITCH;
+#ifndef VG_ABLATE_COMPUTE
 #pragma unroll
         for (int ks = 0; ks < WD_SM / 32; ++ks) {
             bf16x8 a[4], b[4];
@@ -428,6 +432,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_dma_kernel(const vg_wg_desc d,
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+#endif
         rb = rb == WD_NBUF - 1 ? 0 : rb + 1;
         wb = wb == WD_NBUF - 1 ? 0 : wb + 1;
     }

@@ -118,8 +118,26 @@ class DeviceLoader:
         self.last_order: Optional[torch.Tensor] = None           # the epoch's sample order (host), for inspection
 
     def __len__(self) -> int:
-        g = self.batch_size * self.world
-        return (self.indices.numel() + g - 1) // g
+        return sum(1 for _ in self.global_batches(self.indices.numel()))
+
+    def global_batches(self, n: int):
+        """(lo, hi) bounds of THIS rank's shard of every global batch of an epoch of n samples.
+        world == 1: exactly DataLoader(drop_last=False): the ragged last batch is kept (vaegan_code.py:67).
+        world  > 1: every rank must take the same number of steps with the SAME number of rows -- a rank without
+        rows would miss the gradient all-reduce its peers wait in, and unequal shards make SUM/world differ from the
+        global-batch gradient (ddp.py) and break the SyncBN element count.  The ragged last global batch is therefore
+        cut down to the largest multiple of `world` (at most world-1 samples of an epoch are skipped; they come back
+        in the next epoch's shuffle) and dropped when it has fewer samples than ranks."""
+        B, W, r = self.batch_size, self.world, self.rank
+        for start in range(0, n, B * W):
+            stop = min(n, start + B * W)
+            if W == 1:
+                yield start, stop
+                continue
+            per = (stop - start) // W                                      # equal shards, remainder skipped
+            if per == 0:
+                return
+            yield start + r * per, start + (r + 1) * per
 
     def epoch_order(self) -> torch.Tensor:
         """Consumes the default RNG exactly as one ``iter(DataLoader)`` + first ``next()`` does."""
@@ -138,16 +156,7 @@ class DeviceLoader:
         order = self.epoch_order()
         self.last_order = order
         dev_order = order.to(self.dataset.images.device)                   # one small H2D copy per epoch
-        n, B, W, r = order.numel(), self.batch_size, self.world, self.rank
-        for start in range(0, n, B * W):
-            stop = min(n, start + B * W)
-            if W == 1:
-                lo, hi = start, stop
-            else:
-                per = (stop - start + W - 1) // W                          # ragged last global batch: near-equal shards
-                lo, hi = min(stop, start + r * per), min(stop, start + (r + 1) * per)
-                if stop - start < W:                                       # fewer samples than ranks: nobody steps
-                    return
+        for lo, hi in self.global_batches(order.numel()):
             yield self.dataset.batch(dev_order[lo:hi])
 
 

@@ -36,6 +36,21 @@ def side_stream(device) -> "torch.cuda.Stream":
     return _SIDE[key]
 
 
+def fused_pair(a: torch.Tensor, b: torch.Tensor):
+    """[rows_a + rows_b, ...] view over two row-blocks that lie back to back in one allocation (how optim.Adam homes
+    the Encoder's fc_mu / fc_logvar parameters and gradients), else None."""
+    if a is None or b is None or a.shape[1:] != b.shape[1:] or a.dtype != b.dtype:
+        return None
+    if not (a.is_contiguous() and b.is_contiguous()):
+        return None
+    if b.data_ptr() != a.data_ptr() + a.numel() * a.element_size():
+        return None
+    if a.untyped_storage().data_ptr() != b.untyped_storage().data_ptr():
+        return None
+    stride = a.stride() if a.dim() > 1 else (1,)
+    return torch.as_strided(a, (a.shape[0] + b.shape[0],) + tuple(a.shape[1:]), stride)
+
+
 def bump_weights_epoch(params) -> None:
     """Called by optim.Adam after it rewrote `params` behind torch's back (raw-pointer kernel): packed operand
     copies of exactly these parameters become stale (a global counter would re-pack E and G every time D steps)."""
@@ -86,6 +101,21 @@ class GradSink:
     def __init__(self, direct: bool):
         self.direct = direct
         self.out: Dict[int, torch.Tensor] = {}
+
+    def pair(self, pa: torch.Tensor, pb: torch.Tensor):
+        """Gradient tensors of two parameters that one kernel writes as a fused [rows_a + rows_b, ...] block
+        -> (grad_a, grad_b, accumulate).  direct: the optimizer's views (back to back when it homed the pair so);
+        collected: one fresh allocation split in two."""
+        if not self.direct:
+            t = torch.empty((pa.shape[0] + pb.shape[0],) + tuple(pa.shape[1:]), dtype=pa.dtype, device=pa.device)
+            ga, gb = t[:pa.shape[0]], t[pa.shape[0]:]
+            self.out[id(pa)], self.out[id(pb)] = ga, gb
+            return ga, gb, False
+        ga, acc_a = self.get(pa)
+        gb, acc_b = self.get(pb)
+        if acc_a != acc_b:
+            raise RuntimeError("fused parameter pair with different accumulation state")
+        return ga, gb, acc_a
 
     def get(self, param: torch.Tensor):
         """-> (tensor to write, accumulate flag)"""
@@ -169,8 +199,10 @@ class StackEngine:
         for i, st in enumerate(self.stages):
             ent = packs[i]
             if st.kind == "linear2":
-                torch.cat([st.conv.weight.detach(), st.conv2.weight.detach()], 0, out=ent["wcat"])
-                torch.cat([st.conv.bias.detach(), st.conv2.bias.detach()], 0, out=ent["bias"])
+                if not ent["fused"]:            # parameters not homed back to back (foreign optimizer): device copies
+                    n1 = st.conv.weight.shape[0]
+                    ent["wcat"][:n1].copy_(st.conv.weight.detach()), ent["wcat"][n1:].copy_(st.conv2.weight.detach())
+                    ent["bias"][:n1].copy_(st.conv.bias.detach()), ent["bias"][n1:].copy_(st.conv2.bias.detach())
             else:
                 ent["bias"] = st.conv.bias.detach() if st.has_bias else None
         ops.pack_weights_multi(self._pack_table, self._pack_n, self._pack_max, self.dtype)
@@ -185,8 +217,15 @@ class StackEngine:
         for i, st in enumerate(self.stages):
             ent = packs.setdefault(i, {})
             if st.kind == "linear2":
-                ent["wcat"] = torch.cat([st.conv.weight.detach(), st.conv2.weight.detach()], 0)
-                ent["bias"] = torch.cat([st.conv.bias.detach(), st.conv2.bias.detach()], 0)
+                wv = fused_pair(st.conv.weight.detach(), st.conv2.weight.detach())
+                bv = fused_pair(st.conv.bias.detach(), st.conv2.bias.detach())
+                ent["fused"] = wv is not None and bv is not None
+                if ent["fused"]:                # [fc_mu | fc_logvar] is a view into the optimizer's flat buffer
+                    ent["wcat"], ent["bias"] = wv, bv
+                else:
+                    n1, n2 = st.conv.weight.shape[0], st.conv2.weight.shape[0]
+                    ent["wcat"] = torch.empty(n1 + n2, st.conv.weight.shape[1], dtype=torch.float32, device=dev)
+                    ent["bias"] = torch.empty(n1 + n2, dtype=torch.float32, device=dev)
                 w = ent["wcat"]
             else:
                 w = st.conv.weight.detach()
@@ -284,10 +323,23 @@ class StackEngine:
         return a, (ctx, B, train)
 
     # ---- backward ---------------------------------------------------------------------------------
-    def backward(self, ctxpack, dout: torch.Tensor, need_dx: bool, sink: GradSink, param_grads: bool = True):
+    def param_stage(self) -> Dict[int, int]:
+        """id(parameter) -> index of the stage whose backward produces its gradient (ddp bucket planning)."""
+        out = {}
+        for i, st in enumerate(self.stages):
+            for m in (st.conv, st.conv2, st.bn):
+                if m is not None:
+                    for p in m.parameters(recurse=False):
+                        out[id(p)] = i
+        return out
+
+    def backward(self, ctxpack, dout: torch.Tensor, need_dx: bool, sink: GradSink, param_grads: bool = True,
+                 on_grads=None):
         """dout: gradient w.r.t. forward()'s output.  Returns the gradient w.r.t. the NHWC input (or None).
         param_grads=False skips every weight/bias/BN-parameter gradient (legal when the caller discards
-        them, e.g. the generator-loss pass through the discriminator)."""
+        them, e.g. the generator-loss pass through the discriminator).
+        on_grads(i): called right after every parameter gradient of stage i has been enqueued (stages run
+        last-to-first) -- the data-parallel trainer launches a gradient bucket's all-reduce from it."""
         ctx, B, train = ctxpack
         if not train:
             raise RuntimeError("backward through an eval-mode network is not supported (the reference never does it)")
@@ -306,6 +358,8 @@ class StackEngine:
                 if param_grads:
                     gw, acc = sink.get(st.conv.weight)
                     ops.dot_wgrad(c["x"], dlogit, gw, B, K, G.padc(st.cin, dt), st.hin * st.hin, acc, dt)
+                    if on_grads is not None:
+                        on_grads(i)
                 dA = dx
                 continue
             Y, rows, OC = c["Y"], c["rows"], c["OC"]
@@ -332,6 +386,8 @@ class StackEngine:
                     with torch.cuda.stream(side):
                         self._param_grads(i, st, c, dY, B, rows, OC, sink)
                     held.append(dY)
+                if on_grads is not None and side is None:
+                    on_grads(i)
             if want_dx:
                 ggd, _ = self.spec(i, B, "dgrad")
                 mask = None
@@ -355,21 +411,24 @@ class StackEngine:
         dt = self.dtype
         wg = self.spec(i, B, "wgrad")
         if st.kind == "linear2":
+            # one wgrad / one bias reduction for the fused [fc_mu | fc_logvar] head, written straight into the pair's
+            # gradient storage when the two gradients lie back to back (optim.Adam's flat buffer; GradSink.pair)
+            (gw1, gw2, accw), (gb1, gb2, accb) = sink.pair(st.conv.weight, st.conv2.weight), sink.pair(st.conv.bias, st.conv2.bias)
+            fw, fb = fused_pair(gw1, gw2), fused_pair(gb1, gb2)
+            if fw is not None and fb is not None:
+                ops.wgrad(wg, dY, c["x"], fw, accw, dt, alg=st.alg(B, dt))
+                ops.bias_grad(dY, rows, OC, st.cout, fb, accb, dt)
+                return
             N1 = st.conv.weight.shape[0]
             tmp = torch.empty(st.cout, st.conv.weight.shape[1], dtype=torch.float32, device=dY.device)
             ops.wgrad(wg, dY, c["x"], tmp, False, dt, alg=st.alg(B, dt))
             tb = torch.empty(st.cout, dtype=torch.float32, device=dY.device)
             ops.bias_grad(dY, rows, OC, st.cout, tb, False, dt)
-            dsts, srcs = [], []
-            for m, sl in ((st.conv, slice(0, N1)), (st.conv2, slice(N1, st.cout))):
-                for prm, src in ((m.weight, tmp[sl]), (m.bias, tb[sl])):
-                    g, acc = sink.get(prm)
-                    if acc:
-                        ops.axpy(g, src.contiguous(), 1.0, out=g)
-                    else:
-                        dsts.append(g), srcs.append(src.view(g.shape))
-            if dsts:
-                torch._foreach_copy_(dsts, srcs)            # one multi-tensor launch instead of four device copies
+            for g, src, acc in ((gw1, tmp[:N1], accw), (gw2, tmp[N1:], accw), (gb1, tb[:N1], accb), (gb2, tb[N1:], accb)):
+                if acc:
+                    ops.axpy(g, src.contiguous(), 1.0, out=g)
+                else:
+                    g.copy_(src.view(g.shape))                 # contiguous device copy (hipMemcpyAsync), no ATen kernel
             return
         gw, acc = sink.get(st.conv.weight)
         if st.kind == "conv":

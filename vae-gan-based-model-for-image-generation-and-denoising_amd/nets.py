@@ -219,6 +219,10 @@ class Encoder(_EngineNet):
         self.latent_dim = latent_dim
         self.fc_mu = Linear(self.flatten_size, latent_dim)
         self.fc_logvar = Linear(self.flatten_size, latent_dim)
+        # the two heads run as ONE GEMM on [fc_mu | fc_logvar]: ask the optimizer to home them back to back in its
+        # flat buffers (optim.Adam), so the fused operand / gradient is a VIEW and no concatenation is ever launched
+        self.fc_logvar.weight._vg_follows = self.fc_mu.weight
+        self.fc_logvar.bias._vg_follows = self.fc_mu.bias
         stages = []
         hin = self._img
         for blk, hout in zip(self.cnn, self._sizes):

@@ -23,10 +23,15 @@ def _need_cuda(*ts):
 
 
 class _Workspace:
-    """Grow-only scratch buffers, one per (device, tag); all users are ordered on one stream."""
+    """Grow-only scratch buffers, one per (device, tag); all users are ordered on one stream.
+    A buffer that is outgrown is RETIRED, never freed: captured hipGraphs (trainer.train_step_graphed, the sibling
+    trainers) hold raw pointers into the buffers that existed when they were captured, and a later, larger eager
+    call (another trainer, a bigger validation batch) must not hand that memory back to the allocator under them.
+    Growth is geometric, so the retired buffers sum to less than four times the live one."""
 
     def __init__(self):
         self.bufs = {}
+        self.retired = []
 
     def get(self, tag: str, nbytes: int, device) -> torch.Tensor:
         key = (tag, str(device))
@@ -35,6 +40,8 @@ class _Workspace:
             n = max(int(nbytes * 1.25) // 4 + 64, 1 << 16)
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError(f"workspace '{tag}' would grow during graph capture; run a warm-up step first")
+            if buf is not None:
+                self.retired.append(buf)
             buf = torch.empty(n, dtype=torch.float32, device=device)
             self.bufs[key] = buf
         return buf
@@ -86,6 +93,72 @@ def empty_act(shape, dtype: int, device) -> torch.Tensor:
     return torch.empty(shape, dtype=TORCH_DT[dtype], device=device)
 
 
+def zeros_f32(n: int, device) -> torch.Tensor:
+    """f32 zeros through hipMemsetAsync (no ATen fill kernel)."""
+    t = torch.empty(n, dtype=torch.float32, device=device)
+    L.check(L.load().vg_memset_zero(t.data_ptr(), n * 4, L.stream_ptr()), "vg_memset_zero")
+    return t
+
+
+def memset_zero(t: torch.Tensor) -> None:
+    _need_cuda(t)
+    L.check(L.load().vg_memset_zero(t.data_ptr(), t.numel() * t.element_size(), L.stream_ptr()), "vg_memset_zero")
+
+
+class NoiseDraw:
+    """One of the N(0,1) draws of an iteration, generated inside the kernel that consumes it (vg_*_rng)."""
+    __slots__ = ("state", "draw")
+
+    def __init__(self, state: torch.Tensor, draw: int):
+        self.state, self.draw = state, draw
+
+
+class NoiseStream:
+    """Device-resident generator for the in-kernel draws (include/vaegan_hip.h "In-kernel N(0,1) noise"):
+    int64[2] = {seed, iteration counter}.  advance() is a one-thread kernel, captured with the iteration."""
+
+    def __init__(self, device, seed: int):
+        self.seed = int(seed)
+        self.state = torch.tensor([self.seed & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=device)
+        if not self.state.is_cuda:
+            raise RuntimeError("NoiseStream lives on the MI355X ('cuda'); there is no CPU path")
+
+    def advance(self) -> None:
+        L.check(L.load().vg_rng_advance(self.state.data_ptr(), L.stream_ptr()), "vg_rng_advance")
+
+    def draw(self, k: int) -> NoiseDraw:
+        return NoiseDraw(self.state, k)
+
+    def randn(self, shape, k: int) -> torch.Tensor:
+        """Materialise draw k of the current iteration (exactly what the *_rng kernels consume)."""
+        out = torch.empty(shape, dtype=torch.float32, device=self.state.device)
+        L.check(L.load().vg_randn(out.data_ptr(), out.numel(), self.state.data_ptr(), k, L.stream_ptr()), "vg_randn")
+        return out
+
+    def get_state(self):
+        return self.state.clone()
+
+    def set_state(self, st: torch.Tensor) -> None:
+        self.state.copy_(st.to(self.state.device))
+
+
+_NOISE = {}
+
+
+def default_noise(device) -> NoiseStream:
+    """Per-device stream seeded from torch's device generator seed (utils.configure_seed / torch.cuda.manual_seed
+    govern it, as they govern torch.randn_like in the reference); re-seeding torch starts a new stream."""
+    key = str(device)
+    seed = torch.cuda.initial_seed()
+    ns = _NOISE.get(key)
+    if ns is None or ns.seed != seed:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("the noise stream cannot be (re)created during graph capture; run a warm-up step first")
+        ns = NoiseStream(device, seed)
+        _NOISE[key] = ns
+    return ns
+
+
 # ---------------------------------------------------------------------------------------------
 def pack_weights(pk: PackSpec, w: torch.Tensor, dtype: int, out: torch.Tensor = None) -> torch.Tensor:
     _need_cuda(w, out)
@@ -134,7 +207,7 @@ _ZEROS = {}
 def zero_page(device) -> torch.Tensor:
     z = _ZEROS.get(str(device))
     if z is None:
-        z = torch.zeros(64, dtype=torch.float32, device=device)      # 256 zero bytes
+        z = zeros_f32(64, device)                                     # 256 zero bytes
         _ZEROS[str(device)] = z
     return z
 
@@ -334,9 +407,14 @@ def bias_grad(dy, rows, C, NC, dbias, accumulate, dtype):
 
 # ---------------------------------------------------------------------------------------------
 def nchw_to_nhwc(x, CP, dtype, eps=None, sigma=0.0, out=None):
-    _need_cuda(x, eps, out)
+    """eps: None, an NCHW f32 noise tensor, or a NoiseDraw (generated inside the kernel)."""
+    _need_cuda(x, None if isinstance(eps, NoiseDraw) else eps, out)
     B, C, H, W = x.shape
     y = out if out is not None else empty_act((B, H, W, CP), dtype, x.device)
+    if isinstance(eps, NoiseDraw):
+        L.check(L.load().vg_nchw_to_nhwc_rng(x.data_ptr(), eps.state.data_ptr(), eps.draw, sigma, y.data_ptr(), B, C, H,
+                                             W, CP, dtype, L.stream_ptr()), "vg_nchw_to_nhwc_rng")
+        return y
     L.check(L.load().vg_nchw_to_nhwc(x.data_ptr(), L.ptr(eps), sigma, y.data_ptr(), B, C, H, W, CP, dtype,
                                      L.stream_ptr()), "vg_nchw_to_nhwc")
     return y
@@ -389,11 +467,17 @@ def nhwc_to_nchw(x, C, dtype, apply_tanh=False):
 
 def nhwc_tanh_to_nchw_noisy(x, C, eps, sigma, out_noisy, dtype):
     """x NHWC (pre-tanh) -> (tanh(x) as NCHW f32, tanh(x) + sigma*eps written into out_noisy [B,H,W,CP])."""
-    _need_cuda(x, eps, out_noisy)
+    rng = isinstance(eps, NoiseDraw)
+    _need_cuda(x, None if rng else eps, out_noisy)
     B, H, W, CP = x.shape
-    if out_noisy.numel() != x.numel() or eps.numel() != B * C * H * W:
+    if out_noisy.numel() != x.numel() or (not rng and eps.numel() != B * C * H * W):
         raise RuntimeError("nhwc_tanh_to_nchw_noisy: shape mismatch")
     y = torch.empty(B, C, H, W, dtype=torch.float32, device=x.device)
+    if rng:
+        L.check(L.load().vg_nhwc_tanh_to_nchw_noisy_rng(x.data_ptr(), y.data_ptr(), eps.state.data_ptr(), eps.draw, sigma,
+                                                        out_noisy.data_ptr(), B, C, H, W, CP, dtype, L.stream_ptr()),
+                "vg_nhwc_tanh_to_nchw_noisy_rng")
+        return y
     L.check(L.load().vg_nhwc_tanh_to_nchw_noisy(x.data_ptr(), y.data_ptr(), eps.data_ptr(), sigma, out_noisy.data_ptr(),
                                                 B, C, H, W, CP, dtype, L.stream_ptr()), "vg_nhwc_tanh_to_nchw_noisy")
     return y
@@ -421,10 +505,16 @@ def nchw_grad_to_nhwc(dy, tanh_out, CP, dtype):
 
 
 def reparam_forward(mulv, eps, L_dim, ZP, dtype):
-    _need_cuda(mulv, eps)
+    rng = isinstance(eps, NoiseDraw)
+    _need_cuda(mulv, None if rng else eps)
     B, MP = mulv.shape[0], mulv.shape[-1]
     z = empty_act((B, 1, 1, ZP), dtype, mulv.device)
     lvc = torch.empty(B, L_dim, dtype=torch.float32, device=mulv.device)
+    if rng:
+        L.check(L.load().vg_reparam_forward_rng(mulv.data_ptr(), eps.state.data_ptr(), eps.draw, z.data_ptr(),
+                                                lvc.data_ptr(), B, L_dim, MP, ZP, dtype, L.stream_ptr()),
+                "vg_reparam_forward_rng")
+        return z, lvc
     L.check(L.load().vg_reparam_forward(mulv.data_ptr(), eps.data_ptr(), z.data_ptr(), lvc.data_ptr(), B, L_dim, MP,
                                         ZP, dtype, L.stream_ptr()), "vg_reparam_forward")
     return z, lvc
@@ -442,6 +532,11 @@ def reparam_kl_backward(mulv, lvc, eps, dz, kl_scale, L_dim, dtype):
     B, MP = mulv.shape[0], mulv.shape[-1]
     ZP = dz.shape[-1]
     dmulv = torch.empty_like(mulv)
+    if isinstance(eps, NoiseDraw):
+        L.check(L.load().vg_reparam_kl_backward_rng(mulv.data_ptr(), lvc.data_ptr(), eps.state.data_ptr(), eps.draw,
+                                                    dz.data_ptr(), kl_scale, dmulv.data_ptr(), B, L_dim, MP, ZP, dtype,
+                                                    L.stream_ptr()), "vg_reparam_kl_backward_rng")
+        return dmulv
     L.check(L.load().vg_reparam_kl_backward(mulv.data_ptr(), lvc.data_ptr(), eps.data_ptr(), dz.data_ptr(), kl_scale,
                                             dmulv.data_ptr(), B, L_dim, MP, ZP, dtype, L.stream_ptr()),
             "vg_reparam_kl_backward")

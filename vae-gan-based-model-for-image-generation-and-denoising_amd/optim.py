@@ -38,10 +38,36 @@ class Adam:
                 raise RuntimeError("all parameters of one optimizer must live on one device")
         self.defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False)
         self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
-        self.offsets, n = [], 0
-        for p in self.params:
-            self.offsets.append(n)
-            n += (p.numel() + 3) // 4 * 4                      # keep every parameter 16-byte aligned
+        # Placement in the flat buffers.  Default: parameter order.  A parameter tagged `_vg_follows = other` (the
+        # Encoder's fc_logvar after fc_mu, nets.py) is homed directly behind `other`, so that the pair forms one
+        # contiguous [2N, ...] operand.  Indices in state_dict() stay those of self.params.
+        ids = {id(p): i for i, p in enumerate(self.params)}
+        followers = {}
+        for i, p in enumerate(self.params):
+            q = getattr(p, "_vg_follows", None)
+            if q is not None and id(q) in ids and ids[id(q)] != i:
+                followers.setdefault(ids[id(q)], []).append(i)
+        placed, order = set(), []
+
+        def place(i):
+            if i in placed:
+                return
+            placed.add(i)
+            order.append(i)
+            for j in followers.get(i, ()):
+                place(j)
+
+        for i, p in enumerate(self.params):
+            q = getattr(p, "_vg_follows", None)
+            if q is not None and id(q) in ids and ids[id(q)] != i and ids[id(q)] not in placed:
+                continue                                      # comes right after its leader
+            place(i)
+        for i in range(len(self.params)):
+            place(i)
+        self.offsets, n = [0] * len(self.params), 0
+        for i in order:
+            self.offsets[i] = n
+            n += (self.params[i].numel() + 3) // 4 * 4         # keep every parameter 16-byte aligned
         self.numel = n
         self.flat_p = torch.zeros(n, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -67,7 +93,7 @@ class Adam:
         """Gradients become zero (one memset).  memset=False only re-arms the 'overwrite on next write' flags --
         enough for the direct engine, which writes every gradient exactly once before accumulating."""
         if memset:
-            self.flat_g.zero_()
+            ops.memset_zero(self.flat_g)
         for p in self.params:
             p._vg_fresh = True
 

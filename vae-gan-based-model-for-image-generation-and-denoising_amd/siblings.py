@@ -109,11 +109,16 @@ class VAETrainer(_Graphed):
         E, Gn, dt = self.E, self.G, self.dt
         B, dev, L = img.shape[0], img.device, E.latent_dim
         img = img.contiguous()
-        if eps_img is None:
-            eps_img = torch.randn_like(img)                                        # :104
-        if eps_z is None:
-            eps_z = torch.randn(B, L, device=dev)                                  # :114
-        losses = torch.zeros(4, dtype=torch.float32, device=dev)
+        if eps_img is None or eps_z is None:
+            # the reference's randn_like draws, generated in HIP (Philox keyed by torch's device seed; the one-thread
+            # advance kernel is captured with the iteration, so graph replays draw fresh noise)
+            noise = ops.default_noise(dev)
+            noise.advance()
+            if eps_img is None:
+                eps_img = noise.randn(tuple(img.shape), 0)                         # :104
+            if eps_z is None:
+                eps_z = noise.randn((B, L), 1)                                     # :114
+        losses = ops.zeros_f32(4, dev)
         sink = GradSink(direct=True)
         noisy_h, _ = ops.noisy_clamp_to_nhwc(img, eps_img, self.sigma, G.padc(img.shape[1], dt), dt)   # :104-105
         mulv, ctxE = E._engine.forward(noisy_h, B, E.training, True)               # :111
@@ -175,8 +180,10 @@ class DCGANTrainer(_GANBase):
         D, dt = self.D, self.dt
         B, dev = real.shape[0], real.device
         if noise is None:
-            noise = torch.randn(B, self.G.nz, 1, 1, device=dev)                    # :203
-        losses = torch.zeros(4, dtype=torch.float32, device=dev)
+            ns = ops.default_noise(dev)
+            ns.advance()
+            noise = ns.randn((B, self.G.nz, 1, 1), 0)                              # :203
+        losses = ops.zeros_f32(4, dev)
         sink = GradSink(direct=True)
         CP = G.padc(D.nc, dt)
         # D(real) -> G(noise) -> D(fake.detach()) in the reference; G's forward does not touch D, so the two D
@@ -225,11 +232,14 @@ class WGANTrainer(_GANBase):
         _need_cuda(real, "WGANTrainer.train_step")
         D, dt = self.D, self.dt
         B, dev, nz = real.shape[0], real.device, self.G.nz
-        if critic_noise is None:
-            critic_noise = torch.randn(self.critic_iters, B, nz, 1, 1, device=dev)
-        if gen_noise is None:
-            gen_noise = torch.randn(B, nz, 1, 1, device=dev)
-        losses = torch.zeros(4, dtype=torch.float32, device=dev)
+        if critic_noise is None or gen_noise is None:
+            ns = ops.default_noise(dev)
+            ns.advance()
+            if critic_noise is None:
+                critic_noise = ns.randn((self.critic_iters, B, nz, 1, 1), 0)
+            if gen_noise is None:
+                gen_noise = ns.randn((B, nz, 1, 1), 1)
+        losses = ops.zeros_f32(4, dev)
         sink = GradSink(direct=True)
         CP = G.padc(D.nc, dt)
         both = ops.empty_act((2 * B, real.shape[2], real.shape[3], CP), dt, dev)

@@ -45,12 +45,79 @@ class VAEGANTrainer:
         self.dt = dts.pop()
         self.latent = encoder.latent_dim
         self.losses = None
+        self.noise = None               # ops.NoiseStream for the in-kernel randn_like draws (created on first use)
+        self._bucket_plans = {}
         self._graph = None              # (key, [hipGraph segments], [collectives between them], static in, static out)
         self._warm_key = None
         self._cut_hook = None           # set while capturing: splits the iteration into graph segments
 
     def train(self):
         self.E.train(), self.G.train(), self.D.train()                                         # :56-58
+
+    def _noise_stream(self, dev):
+        """The generator behind the non-injected draws: torch's device seed (utils.configure_seed /
+        torch.cuda.manual_seed) keys it, as it keys torch.randn_like in the reference; re-seeding torch starts a new
+        stream (and invalidates a captured graph, which holds the old state buffer)."""
+        seed = torch.cuda.initial_seed()
+        if self.noise is None or self.noise.seed != seed:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("noise stream (re)seeded during graph capture")
+            self.noise = ops.NoiseStream(dev, seed)
+            self._graph = None
+        return self.noise
+
+    def _capture_key(self, real, epoch, inject):
+        """Everything a captured graph freezes: shapes, every scalar kernel argument (loss weights, labels, noise
+        sigma, Adam hyper-parameters, the data-parallel gradient scale), the schedule switches and the buffers the
+        launches point at.  A change in any of them re-captures instead of silently replaying stale values."""
+        opts = tuple((o.lr, o.betas, o.eps, o.grad_scale, o.flat_p.data_ptr()) for o in (self.opt_E, self.opt_G, self.opt_D))
+        return (tuple(real.shape), float(self.alpha_kl * min(1.0, epoch / 50)), inject, self.E.training, self.G.training,
+                self.D.training, self.alpha_adv, self.sigma, self.real_label, self.fake_label, self.d_iters,
+                self.elide_dead_grads, self.group_d_passes, id(self.reducer), self.sync_bn, opts,
+                None if self.noise is None or inject else self.noise.state.data_ptr())
+
+    # ---- data-parallel gradient hand-off (ddp.GradReducer) -------------------------------------------------------
+    def _buckets_for(self, opt, net):
+        """Plan `opt`'s gradient buckets once: parameter -> stage whose backward completes its gradient."""
+        key = id(opt)
+        if key not in self._bucket_plans:
+            stage_of = net._engine.param_stage()
+            ready = [stage_of.get(id(p), 0) for p in opt.params]
+            plan = getattr(self.reducer, "plan", None)
+            self._bucket_plans[key] = plan(opt, ready) if plan is not None else None
+        return self._bucket_plans[key]
+
+    def _grad_hook(self, opt, net):
+        """on_grads callback for engine.backward: after stage i's weight gradients are enqueued, launch (behind a
+        graph cut) the all-reduce of every bucket that stage completes.  Stage 0 is left to _finish_reduce, which
+        launches the last bucket and waits in ONE cut (no empty graph segment between two cuts)."""
+        if self.reducer is None or self._buckets_for(opt, net) is None:
+            return None
+        events = {ev for _, _, ev in self._bucket_plans[id(opt)] if ev > 0}
+
+        def hook(i):
+            if i in events:
+                self._cut(lambda: self.reducer.launch_ready(opt, i))
+        return hook
+
+    def _finish_reduce(self, opt, net, wait=True, also_wait=()):
+        """End of `net`'s backward: launch what is left of opt's buckets, optionally wait for all of them."""
+        if self.reducer is None:
+            return
+        bucketed = self._buckets_for(opt, net) is not None
+
+        def fn():
+            if bucketed:
+                self.reducer.launch_ready(opt, 0)
+            elif wait:
+                self.reducer.reduce(opt)
+            else:
+                self.reducer.reduce_async(opt)
+            if wait:
+                self.reducer.wait(opt)
+            for o in also_wait:
+                self.reducer.wait(o)
+        self._cut(fn)
 
     def _cut(self, collective) -> None:
         """A point where the iteration hands gradients to the reducer.  Eager: run the collective now.  While
@@ -70,13 +137,15 @@ class VAEGANTrainer:
         B, dev = real.shape[0], real.device
         L = self.latent
         real = real.contiguous()
-        if eps_z is None:
-            eps_z = torch.randn(B, L, device=dev)                                             # :77
-        if eps_real is None:
-            eps_real = torch.randn_like(real)                                                 # :91
-        if eps_recon is None:
-            eps_recon = torch.randn_like(real)                                                # :92
-        losses = torch.zeros(8, dtype=torch.float32, device=dev)
+        if eps_z is None or eps_real is None or eps_recon is None:
+            # the three randn_like draws (:77, :91, :92) are generated inside the kernels that consume them
+            # (Philox keyed by torch's device seed; vg_rng_advance bumps the iteration counter, also under replay)
+            noise = self._noise_stream(dev)
+            noise.advance()
+            eps_z = noise.draw(0) if eps_z is None else eps_z
+            eps_real = noise.draw(1) if eps_real is None else eps_real
+            eps_recon = noise.draw(2) if eps_recon is None else eps_recon
+        losses = torch.empty(8, dtype=torch.float32, device=dev)     # every slot read later is written (not accumulated) first
         sink = GradSink(direct=True)
 
         # ---- Encode / reparameterise / decode (:74-83) ----
@@ -108,16 +177,15 @@ class VAEGANTrainer:
                 dp = torch.empty_like(p_both)
                 ops.bce_forward_backward(p_both[:B], self.real_label, 1.0, slot, False, True, out=dp[:B])
                 ops.bce_forward_backward(p_both[B:], self.fake_label, 1.0, slot, True, True, out=dp[B:])
-                D._engine.backward(c_both, dp, False, sink)
+                D._engine.backward(c_both, dp, False, sink, on_grads=self._grad_hook(self.opt_D, D))
             else:
                 p_real, c_real = D.engine_forward(real_noisy, B)
                 p_fake, c_fake = D.engine_forward(recon_noisy, B)
                 dp_real = ops.bce_forward_backward(p_real, self.real_label, 1.0, slot, False, True)
                 dp_fake = ops.bce_forward_backward(p_fake, self.fake_label, 1.0, slot, True, True)
                 D._engine.backward(c_real, dp_real, False, sink)
-                D._engine.backward(c_fake, dp_fake, False, sink)
-            if self.reducer is not None:
-                self._cut(lambda: self.reducer.reduce(self.opt_D))
+                D._engine.backward(c_fake, dp_fake, False, sink, on_grads=self._grad_hook(self.opt_D, D))   # the accumulating pass
+            self._finish_reduce(self.opt_D, D)            # D's buckets overlap the rest of its own backward
             self.opt_D.step()
 
         # ---- Generator + VAE loss (:110-117) ----
@@ -132,14 +200,12 @@ class VAEGANTrainer:
         d_noisy = D._engine.backward(c_adv, dp_adv, True, sink, param_grads=not self.elide_dead_grads)
         # d total / d recon = d MSE + d adv through the instance-noise add (:92), then through tanh: one pass
         d_pre = ops.nchw_grad_add_to_nhwc(d_recon, d_noisy, recon, G.padc(Gn.nc, dt), dt)
-        dz = Gn._engine.backward(ctxG, d_pre, True, sink)
-        if self.reducer is not None:
-            self._cut(lambda: self.reducer.reduce_async(self.opt_G))     # overlaps with the encoder's backward
+        dz = Gn._engine.backward(ctxG, d_pre, True, sink, on_grads=self._grad_hook(self.opt_G, Gn))
+        self._finish_reduce(self.opt_G, Gn, wait=False)       # G's last bucket overlaps the encoder's backward
         kl_w = self.alpha_kl * min(1.0, epoch / 50)                                            # :117
         dmulv = ops.reparam_kl_backward(mulv, lvc, eps_z, dz, kl_w / B, L, dt)
-        E._engine.backward(ctxE, dmulv.view(B, 1, 1, -1), False, sink)
-        if self.reducer is not None:
-            self._cut(lambda: (self.reducer.reduce(self.opt_E), self.reducer.wait(self.opt_G)))
+        E._engine.backward(ctxE, dmulv.view(B, 1, 1, -1), False, sink, on_grads=self._grad_hook(self.opt_E, E))
+        self._finish_reduce(self.opt_E, E, also_wait=(self.opt_G,))
         self.opt_E.step()
         self.opt_G.step()
         self.losses = losses
@@ -149,8 +215,9 @@ class VAEGANTrainer:
     def train_step_graphed(self, real: torch.Tensor, epoch: int, eps_z: Optional[torch.Tensor] = None,
                            eps_real: Optional[torch.Tensor] = None,
                            eps_recon: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Same iteration as train_step, replayed from captured hipGraphs (~270 kernel launches become one graph
-        launch per segment).  Every call performs exactly one training iteration: the first call with a new
+        """Same iteration as train_step, replayed from captured hipGraphs (~220 kernel launches become one graph
+        launch per segment).  The returned tensor is the graph's STATIC output buffer: the next call overwrites it
+        (clone it to keep a history of losses).  Every call performs exactly one training iteration: the first call with a new
         (shape, KL weight, noise mode) runs eagerly (it also sizes the workspaces), the second captures and
         replays, later calls replay.  Inputs are copied into static buffers; noise is either injected on every
         call or drawn on the device inside the graph (torch's graph-safe Philox state).
@@ -162,7 +229,9 @@ class VAEGANTrainer:
             raise ValueError("inject all three noise tensors or none")
         if self.sync_bn:        # a collective inside every BatchNorm: run the iteration eagerly (parity mode)
             return self.train_step(real, epoch, eps_z, eps_real, eps_recon)
-        key = (tuple(real.shape), float(self.alpha_kl * min(1.0, epoch / 50)), inject, self.E.training)
+        if not inject:
+            self._noise_stream(real.device)         # exists (and is keyed on the current seed) before the key is formed
+        key = self._capture_key(real, epoch, inject)
         if self._graph is not None and self._graph[0] == key:
             _, graphs, cuts, sin, sout = self._graph
             sin[0].copy_(real)
@@ -179,7 +248,15 @@ class VAEGANTrainer:
         sin = [real.clone()] + ([eps_z.clone(), eps_real.clone(), eps_recon.clone()] if inject else [None] * 3)
         for eng in (self.E._engine, self.G._engine, self.D._engine):
             eng.invalidate()                       # the captured sequence must contain the operand re-packs
+        # Nothing of torch.distributed may be in flight while a stream is capturing: c10d's watchdog thread polls
+        # unfinished collectives with hipEventQuery, which is illegal next to a capture (the abort recorded in round 1).
+        # Structural guard rather than luck: wait for every collective this trainer launched, drain the device, and
+        # REFUSE to capture if the reducer still reports outstanding work.
+        if self.reducer is not None and hasattr(self.reducer, "drain"):
+            self.reducer.drain()
         torch.cuda.synchronize()
+        if self.reducer is not None and getattr(self.reducer, "outstanding", lambda: 0)() != 0:
+            raise RuntimeError("hipGraph capture refused: the gradient reducer still has collectives in flight")
         ticks = [m._engine.pending_bn_ticks for m in (self.E, self.G, self.D)]
         steps = [o.steps for o in (self.opt_E, self.opt_G, self.opt_D)]
         graphs, cuts = [], []
@@ -262,7 +339,9 @@ class VAEGANTrainer:
     def state_dict(self) -> Dict:
         return {"format": 1,
                 "encoder": self.E.state_dict(), "decoder": self.G.state_dict(), "discriminator": self.D.state_dict(),
-                "opt_E": self.opt_E.state_dict(), "opt_Dec": self.opt_G.state_dict(), "opt_Dis": self.opt_D.state_dict()}
+                "opt_E": self.opt_E.state_dict(), "opt_Dec": self.opt_G.state_dict(), "opt_Dis": self.opt_D.state_dict(),
+                # generator state of the in-kernel randn_like draws: [seed, iteration counter] (None: never used)
+                "noise": None if self.noise is None else self.noise.get_state().cpu()}
 
     def load_state_dict(self, sd: Dict) -> None:
         if sd.get("format") != 1:
@@ -271,6 +350,14 @@ class VAEGANTrainer:
         self.D.load_state_dict(sd["discriminator"])
         self.opt_E.load_state_dict(sd["opt_E"]), self.opt_G.load_state_dict(sd["opt_Dec"])
         self.opt_D.load_state_dict(sd["opt_Dis"])
+        if sd.get("noise") is not None:
+            st = sd["noise"]
+            dev = next(self.E.parameters()).device
+            if self.noise is None:
+                self.noise = ops.NoiseStream(dev, int(st[0]))
+                self._graph = None
+            self.noise.seed = int(st[0])
+            self.noise.set_state(st)
 
     def save_checkpoint(self, path: str, **extra) -> None:
         """extra: plain numbers / strings / tensors stored next to the state (e.g. epoch=...)."""
