@@ -319,6 +319,7 @@ def main():
     fam = timer.summary()
     gg = fam.get("gather_gemm", dict(launches=0, ms=1e-9, flops=0, bytes=0))
     wg = fam.get("wgrad", dict(launches=0, ms=1e-9, flops=0, bytes=0))
+    ed = fam.get("edge", dict(launches=0, ms=0.0, flops=0, bytes=0))
     ach = gg["flops"] / (gg["ms"] * 1e-3) / 1e12
     traffic, traffic_src = pmc_traffic(args.dtype)
     roofline = {"bound": "mfma", "kernel": "gg_kernel (gather-GEMM: conv/convT/linear fprop + dgrad)",
@@ -341,6 +342,17 @@ def main():
                           "launches_per_step": wg["launches"] // args.steps,
                           "share_of_step": round(wg["ms"] / args.steps / ms, 3)},
                 "step_alg_tflops": round(ALG_GFLOP_PER_IMAGE.get(S, 0) * B / ms, 2)}
+    # the 3-channel image-side layers (<= 20 FLOP/B, priced against HBM): own kernels, own roofline
+    roofline_edge = None
+    if ed["launches"]:
+        gbs = ed["bytes"] / (ed["ms"] * 1e-3) / 1e9
+        roofline_edge = {"bound": "hbm", "kernel": "edge layers: tnconv_kernel (narrow-N transposed conv, GEMM + col2im), "
+                                                   "ggn_kernel (narrow-K direct conv)",
+                         "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                         "traffic": None, "launches_per_step": ed["launches"] // args.steps,
+                         "avg_launch_us": round(ed["ms"] * 1e3 / ed["launches"], 2),
+                         "alg_mbytes_per_launch": round(ed["bytes"] / ed["launches"] / 1e6, 2),
+                         "share_of_step": round(ed["ms"] / args.steps / ms, 3)}
     out = {"metric": "images/sec/GPU VAE-GAN train step", "value": round(value, 1), "unit": "images/sec",
            "per_gpu": round(value / world, 1), "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -351,6 +363,8 @@ def main():
                       "elide_dead_grads": bool(args.elide_dead_grads), "hip_graph": use_graph},
            "losses": {k: round(v, 5) for k, v in ld.items()},
            "roofline": roofline}
+    if roofline_edge is not None:
+        out["roofline_edge"] = roofline_edge
     if world == 1 and not multi and not args.no_extra_paths:
         del tr, e, g, d, oE, oG, oD
         out["parity_path"] = parity_path(V, S, B, dev, resident)

@@ -40,6 +40,7 @@ extern "C" {
 #define VG_ACT_NONE    0
 #define VG_ACT_RELU    1   /* nn.ReLU(True)          gan_code.py:23-43            */
 #define VG_ACT_LRELU   2   /* nn.LeakyReLU(slope)    main_vae.py:25, gan_code.py:62-82 */
+#define VG_ACT_TANH    3   /* nn.Tanh()              gan_code.py:50 (vg_tnconv epilogue only) */
 
 #define VG_ABI_VERSION 3   /* 2: vg_pack_desc.tile_start, SyncBN / WGAN / data-path entry points; 3: in-kernel noise (vg_*_rng) */
 int vg_abi_version(void);
@@ -97,6 +98,9 @@ typedef struct vg_gg_desc {
 
 /* Number of stats slabs vg_gather_gemm will write for this descriptor (host-only query). */
 int vg_gather_gemm_nparts(const vg_gg_desc* d, int dtype);
+/* Kernel family a launch of this descriptor belongs to (for the roofline accounting of vg_timing_*):
+ * 0 = gather-GEMM (MFMA-bound), 2 = edge layer (3-channel image side, HBM-bound: conv_narrowk.hpp). */
+int vg_gather_gemm_family(const vg_gg_desc* d, int dtype);
 /* Rows (M) covered by one statistics slab = the M edge of the tile the launcher picks (host-only query). */
 int vg_gather_gemm_tile_m(const vg_gg_desc* d, int dtype);
 /* Bytes of split-K workspace this launch can use (0: the launcher will not split K).  Skinny problems -- few
@@ -226,6 +230,35 @@ int vg_act_backward(const void* x, const void* dy, void* dx, int64_t n, int act,
 /* dbias[c] (+)= sum over rows of dy[row][c]  (Conv2d bias grad, main_vae.py:23; Linear bias). */
 int vg_bias_grad(const void* dy, int64_t rows, int C, int NC, float* dbias, int accumulate,
                  float* ws, int ws_capacity, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Edge layers (3-channel side at the image boundary; HBM-bound)
+ * ---------------------------------------------------------------------------------------- */
+/* Narrow-N transposed convolution, bf16:
+ *     Y[b][oy][ox][n] = sum_{c,kh,kw} X[b][iy][ix][c] * W[c][n][kh][kw],  oy = iy*S - P + kh, ox = ix*S - P + kw
+ * = nn.ConvTranspose2d(C, N, K, S, P).forward (the Generator's last layer, gan_code.py:49: C->3, k3 s1 p1) and the
+ * data gradient of nn.Conv2d(N, C, K, S, P) (the image gradient below the Discriminator's first layer,
+ * gan_code.py:61: 3->C, k4 s2 p1, reached by loss.backward() at vaegan_code.py:133).  N <= 4, K*K*N <= 64.
+ * Computed as ONE GEMM per input pixel over the channels, Pm[pix][(kh,kw,n)] = X[pix][:] . Wp[(kh,kw,n)][:], followed
+ * by the K*K-tap col2im sum inside the workgroup's LDS tile: every input byte is read once.
+ * Wp: [K*K*N][Wpitch] bf16, row j = (kh*K + kw)*N + n, = vg_pack_weights with tap_in_n=1 of the [C][N][K][K]
+ * (ConvTranspose2d) / [C][N][K][K]-viewed (Conv2d [Cout=C][Cin=N][K][K]) weight.
+ * Outputs: Y NHWC bf16 [B][OH][OW][OC=8] (channels >= N zero) and/or Y_nchw f32 [B][N][OH][OW].
+ * act = VG_ACT_TANH applies tanh (gan_code.py:50) to both; with noise (eps NCHW f32, or rng+draw: in-kernel
+ * N(0,1)) Y becomes act(.) + sigma*noise while Y_nchw stays act(.) -- vaegan_code.py:83 and :92 in one pass. */
+typedef struct vg_tn_desc {
+    const void* X;          /* [B][IH][IW][C] bf16, C = 32 or 64 */
+    const void* Wp;
+    void* Y;                /* or NULL */
+    float* Y_nchw;          /* or NULL */
+    const float* eps;       /* or NULL */
+    const uint64_t* rng;    /* or NULL */
+    int32_t draw;
+    float sigma;
+    int32_t B, IH, IW, C, N, K, S, P, OH, OW, OC, Wpitch, act;
+} vg_tn_desc;
+int vg_tnconv_supported(const vg_tn_desc* d);     /* 0 if vg_tnconv takes this shape, else the error code */
+int vg_tnconv(const vg_tn_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Layout / pointwise / losses

@@ -222,6 +222,54 @@ def test_layout_noise_tanh(ops, dtype):
                                atol=1e-2 if dtype else 1e-6)
 
 
+@pytest.mark.parametrize("C,N,k,s,p,H,B", [(64, 3, 3, 1, 1, 64, 3),      # Generator's last layer at S=64 (gan_code.py:49)
+                                            (64, 3, 4, 2, 1, 32, 3),      # image gradient below D's first conv, S=64
+                                            (32, 3, 3, 1, 1, 128, 2),     # S=128 members of both
+                                            (32, 3, 4, 2, 1, 64, 2),
+                                            (64, 3, 3, 1, 1, 16, 1),      # whole image in one tile
+                                            (64, 1, 4, 2, 1, 48, 2),      # N=1, rows that do not fill the last tile
+                                            (32, 4, 4, 2, 1, 16, 1)])     # K*K*N = 64: all four column tiles
+def test_edge_layer_transposed_conv_vs_torch(ops, C, N, k, s, p, H, B):
+    """vg_tnconv (GEMM per input pixel + col2im, csrc/edge_conv.hip) against torch's conv_transpose2d in fp64 on the
+    bf16-rounded operands: plain NHWC output, then the fused Tanh / NCHW image / instance-noise epilogue."""
+    g = torch.Generator().manual_seed(C * 100 + k * 10 + H)
+    x = torch.randn(B, C, H, H, generator=g)
+    w = torch.randn(C, N, k, k, generator=g) * 0.05
+    sp = G.tn_spec(B, H, H, C, N, k, s, p, G.BF16, s_n=k * k, s_c=N * k * k)
+    assert sp is not None
+    tn, pk = sp
+    xh = _dev(to_nhwc(x, C), G.BF16, ops)
+    wp = ops.pack_weights(pk, w.to(DEV), G.BF16)
+    ref = F.conv_transpose2d(_q(x, G.BF16), _q(w, G.BF16), stride=s, padding=p)
+    y, _ = ops.tnconv(tn, xh, wp)
+    assert tuple(y.shape) == (B, tn.OH, tn.OW, 8) and (y[..., N:] == 0).all()
+    close(from_nhwc(y.double().cpu(), N), _q(ref, G.BF16), G.BF16, bf16=(1e-2, 8e-3))
+    # fused epilogue: tanh -> NCHW f32, and tanh + sigma*eps -> NHWC bf16 (vaegan_code.py:83, :92)
+    eps = torch.randn(B, N, tn.OH, tn.OW, generator=g)
+    yn, img = ops.tnconv(tn, xh, wp, want_nchw=True, act=3, noise=eps.to(DEV), sigma=0.05)
+    torch.testing.assert_close(img.double().cpu(), torch.tanh(ref), rtol=1e-5, atol=2e-5)       # f32 accumulators: no bf16 rounding before tanh
+    close(from_nhwc(yn.double().cpu(), N), _q(img.double().cpu() + 0.05 * eps.double(), G.BF16), G.BF16, bf16=(1e-2, 4e-3))
+    ns = ops.NoiseStream(DEV, 77)
+    ns.advance()
+    yr, img2 = ops.tnconv(tn, xh, wp, want_nchw=True, act=3, noise=ns.draw(2), sigma=0.05)     # in-kernel draw ==
+    ym, _ = ops.tnconv(tn, xh, wp, want_nchw=True, act=3, noise=ns.randn((B, N, tn.OH, tn.OW), 2), sigma=0.05)   # materialised
+    assert torch.equal(yr, ym) and torch.equal(img2, img)
+    # image only (autograd drop-in path of Generator.forward)
+    none, img3 = ops.tnconv(tn, xh, wp, want_nhwc=False, want_nchw=True, act=3)
+    assert none is None and torch.equal(img3, img)
+
+
+def test_edge_layer_kernel_rejects_what_it_does_not_take(ops):
+    assert G.tn_spec(2, 64, 64, 16, 3, 3, 1, 1, G.BF16, 9, 27) is None          # C = 16 (S=256 members): gather-GEMM
+    assert G.tn_spec(2, 64, 64, 64, 3, 3, 1, 1, G.F32, 9, 27) is None           # exact-f32 parity path: gather-GEMM
+    assert G.tn_spec(2, 64, 64, 64, 8, 3, 1, 1, G.BF16, 9, 72) is None          # not narrow
+    assert G.tn_spec(2, 31, 31, 64, 3, 3, 1, 1, G.BF16, 9, 27) is None          # rows are not whole 16-pixel groups
+    tn, pk = G.tn_spec(1, 16, 16, 64, 3, 3, 1, 1, G.BF16, 9, 27)
+    x = torch.zeros(1, 16, 16, 64, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        ops.tnconv(tn, x, torch.zeros(5, dtype=torch.bfloat16, device=DEV))
+
+
 def test_in_kernel_noise_equals_materialised_draws_and_is_standard_normal(ops):
     """vg_*_rng (the three randn_like draws of vaegan_code.py:77,91,92 generated inside the consuming kernels) against
     the same kernels fed with vg_randn's materialisation of the same (seed, iteration, draw): bitwise.  Plus the

@@ -13,7 +13,7 @@ from ctypes import (POINTER, Structure, byref, c_char_p, c_double, c_float, c_in
 import torch  # noqa: F401  (must be loaded before the HIP library, see module docstring)
 
 VG_F32, VG_BF16 = 0, 1
-VG_ACT_NONE, VG_ACT_RELU, VG_ACT_LRELU = 0, 1, 2
+VG_ACT_NONE, VG_ACT_RELU, VG_ACT_LRELU, VG_ACT_TANH = 0, 1, 2, 3
 VG_MAX_PHASE = 4
 ABI_VERSION = 3
 
@@ -48,6 +48,15 @@ class WGDesc(Structure):
                 ("s_np", c_int32), ("s_cq", c_int32), ("s_t", c_int32), ("accumulate", c_int32), ("zeros", c_void_p)]
 
 
+class TNDesc(Structure):
+    """vg_tn_desc."""
+    _fields_ = [("X", c_void_p), ("Wp", c_void_p), ("Y", c_void_p), ("Y_nchw", c_void_p), ("eps", c_void_p),
+                ("rng", c_void_p), ("draw", c_int32), ("sigma", c_float),
+                ("B", c_int32), ("IH", c_int32), ("IW", c_int32), ("C", c_int32), ("N", c_int32), ("K", c_int32),
+                ("S", c_int32), ("P", c_int32), ("OH", c_int32), ("OW", c_int32), ("OC", c_int32),
+                ("Wpitch", c_int32), ("act", c_int32)]
+
+
 class PackDesc(Structure):
     """vg_pack_desc."""
     _fields_ = [("src", c_void_p), ("dst", c_void_p),
@@ -67,6 +76,7 @@ SIGNATURES = {
     "vg_timing_collect": (c_int, [_I, POINTER(c_double), POINTER(c_int)]),
     "vg_gather_gemm_nparts": (c_int, [POINTER(GGDesc), _I]),
     "vg_gather_gemm_tile_m": (c_int, [POINTER(GGDesc), _I]),
+    "vg_gather_gemm_family": (c_int, [POINTER(GGDesc), _I]),
     "vg_gather_gemm_ws_bytes": (c_int64, [POINTER(GGDesc), _I]),
     "vg_gather_gemm": (c_int, [POINTER(GGDesc), _I, _P]),
     "vg_wgrad_ws_bytes": (c_int64, [POINTER(WGDesc), _I]),
@@ -116,6 +126,8 @@ SIGNATURES = {
     "vg_reparam_forward_rng": (c_int, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
     "vg_reparam_kl_backward_rng": (c_int, [_P, _P, _P, _I, _P, _F, _P, _I, _I, _I, _I, _I, _P]),
     "vg_memset_zero": (c_int, [_P, _L, _P]),
+    "vg_tnconv_supported": (c_int, [POINTER(TNDesc)]),
+    "vg_tnconv": (c_int, [POINTER(TNDesc), _P]),
 }
 
 LIB_PATH = os.environ.get("VG_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libvaegan_hip.so")

@@ -100,7 +100,7 @@ struct VgTiming {
     bool on = false;
     std::mutex mu;
     std::vector<hipEvent_t> pool;                                 // free events
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> rec[2];         // family 0: gather-GEMM, 1: wgrad
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> rec[3];         // family 0: gather-GEMM, 1: wgrad, 2: edge layers (HBM-bound)
 };
 VgTiming& vg_timing();
 

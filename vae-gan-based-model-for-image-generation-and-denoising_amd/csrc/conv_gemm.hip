@@ -615,6 +615,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 
 #include "conv_patch.hpp"
+#include "conv_narrowk.hpp"
 
 struct TileCfg { int bm, bn; };
 struct SplitK { int ksplit, sps; int64_t ws_bytes; };
@@ -653,6 +654,7 @@ inline TileCfg pick_tile(const vg_gg_desc* d, bool bf16 = false) {
     const int N = d->N;
     const int ph = d->nphase;
     const int need = min_wgs();
+    if (bf16 && narrowk_ok(d, VG_BF16)) return {NK_BM, N};       // 3-channel-input edge layers: ggn_kernel, all N per workgroup
     if (N <= 16) return {256, 16};
     if (N <= 32) return {128, 32};
     // 256 x 128 exists only as the patch kernel (bf16, LDS-DMA): 8 waves share every weight tile
@@ -756,6 +758,12 @@ extern "C" int vg_gather_gemm_nparts(const vg_gg_desc* d, int dtype) {
     return d->nphase * ((M + t.bm - 1) / t.bm);
 }
 
+extern "C" int vg_gather_gemm_family(const vg_gg_desc* d, int dtype) {
+    int rc = validate(d, dtype);
+    if (rc) return rc;
+    return narrowk_ok(d, dtype) ? 2 : 0;
+}
+
 extern "C" int vg_gather_gemm_tile_m(const vg_gg_desc* d, int dtype) {
     int rc = validate(d, dtype);
     if (rc) return rc;
@@ -778,6 +786,7 @@ extern "C" int vg_gather_gemm(const vg_gg_desc* d, int dtype, void* stream) {
         VG_CHECK_ARG(d->stats_capacity >= d->nphase * ((M + t.bm - 1) / t.bm), VG_EINVAL);
     }
     if (dtype == VG_F32) return dispatch<VG_F32>(d, t, vg_stream(stream), sk);
+    if (narrowk_ok(d, dtype)) return launch_narrowk(d, vg_stream(stream));
     PatchGeo pg;
     if ((t.bm == 128 || t.bm == 256) && (t.bn == GP_BN || (t.bn == 64 && patch64())) && sk.ksplit <= 1 &&
         use_patch() && use_dma() && d->zeros != nullptr && patch_geometry(d, t.bm, &pg)) {

@@ -547,6 +547,59 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const vg_wg_desc d, i
     }
 }
 
+// Streaming form of the slab reduce for the weight-heavy layers (few splits, large dW: the Generator's 1024->512 and
+// 512->256 layers, the Discriminator's 256->512): a block owns one np row x 64 gathered channels x all T <= 16 taps.
+// Thread (tap, 4 channels) sums its float4 over the splits with whole 256-byte slab rows per tap (coalesced, 4 splits in
+// flight), the [tap][cq] -> [cq][tap] turn happens in LDS, and the block writes ONE contiguous 64*T-float run of the
+// reference weight layout ([np][cq][kh][kw]: s_cq == T, s_t == 1).  With one split this is the pure layout change the
+// generic kernel spent 32 us on (67 MB at 2 TB/s); same fixed summation order (k = 0, 1, ...), bitwise reproducible.
+__global__ __launch_bounds__(256) void wgrad_reduce_t_kernel(const vg_wg_desc d, int nsplit, int NPpad, int ldk) {
+    __shared__ __attribute__((aligned(16))) float tile[64 * 16];
+    const int T = d.TH * d.TW;
+    const int cqt = d.QC >> 6;                                   // 64-channel tiles per np row
+    const int np = blockIdx.x / cqt, cq0 = (blockIdx.x - np * cqt) << 6;
+    const int t = threadIdx.x >> 4, c4 = threadIdx.x & 15;
+    float4 s = {0.f, 0.f, 0.f, 0.f};
+    if (t < T) {
+        const float* src = d.ws + (int64_t)np * ldk + (int64_t)t * d.QC + cq0 + c4 * 4;
+        const int64_t stride = (int64_t)NPpad * ldk;
+        int k = 0;
+        for (; k + 4 <= nsplit; k += 4) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(src + (k + u) * stride);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+        }
+        for (; k < nsplit; ++k) {
+            const float4 v = *reinterpret_cast<const float4*>(src + k * stride);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        float* tl = tile + (c4 * 4) * T + t;
+        tl[0] = s.x; tl[T] = s.y; tl[2 * T] = s.z; tl[3 * T] = s.w;
+    }
+    __syncthreads();
+    float* dst = d.dW + (int64_t)np * d.s_np + (int64_t)cq0 * T;
+    for (int i = threadIdx.x * 4; i < 64 * T; i += 1024) {       // 64*T % 4 == 0; run start is 16-byte aligned (T*cq0 % 4 == 0)
+        float4 v = *reinterpret_cast<const float4*>(tile + i);
+        if (d.accumulate) {
+            const float4 o = *reinterpret_cast<const float4*>(dst + i);
+            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        }
+        *reinterpret_cast<float4*>(dst + i) = v;
+    }
+}
+
+// the streaming reduce takes: <= 16 taps, contiguous taps, channel stride == tap count, whole 64-channel tiles,
+// 16-byte aligned runs
+inline bool Ttaps_ok(const vg_wg_desc* d) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("VG_WG_REDUCE_T"); on = e ? atoi(e) : 1; }
+    const int T = d->TH * d->TW;
+    return on && T <= 16 && d->s_t == 1 && d->s_cq == T && d->QC % 64 == 0 && d->NQ == d->QC && (d->s_np % 4) == 0 &&
+           ((64 * T) % 4) == 0 && vg_aligned16(d->dW);
+}
+
 struct Plan { int tiles_kq, tiles_np, nsplit, rows_per_split, KQ, NPpad, tile; int64_t ws_bytes; };
 
 inline int wg_target() {
@@ -626,6 +679,12 @@ extern "C" int vg_wgrad(const vg_wg_desc* d, int dtype, void* stream) {
         vg_launch_timed(1, wgrad_bf16_kernel, grid, dim3(256), 0, s, *d, p.rows_per_split, p.KQ, p.NPpad);
     rc = VG_LAUNCH_RC();
     if (rc) return rc;
+    // weight-heavy layers with few splits: streaming transpose-reduce (one contiguous run of dW per block)
+    if (dtype == VG_BF16 && Ttaps_ok(d) && p.nsplit <= 16 && (int64_t)d->NP * (d->QC >> 6) >= 256) {
+        hipLaunchKernelGGL(wgrad_reduce_t_kernel, dim3((unsigned)(d->NP * (d->QC >> 6))), dim3(256), 0, s, *d, p.nsplit,
+                           p.NPpad, p.tiles_kq * p.tile);
+        return VG_LAUNCH_RC();
+    }
     const bool vec = (d->NQ % 4 == 0) && (d->QC % 4 == 0);
     const int VC = vec ? 4 : 1;
     const int64_t total = (int64_t)d->NP * ((d->NQ + VC - 1) / VC);

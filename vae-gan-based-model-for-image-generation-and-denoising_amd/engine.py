@@ -21,7 +21,7 @@ import torch
 
 from . import geometry as G
 from . import ops
-from ._lib import VG_ACT_LRELU, VG_ACT_NONE, VG_ACT_RELU
+from ._lib import VG_ACT_LRELU, VG_ACT_NONE, VG_ACT_RELU, VG_ACT_TANH
 
 BN_MOMENTUM, BN_EPS = 0.1, 1e-5       # nn.BatchNorm2d defaults (main_vae.py:24, gan_code.py:22)
 
@@ -171,6 +171,21 @@ class StackEngine:
             self._specs[key] = sp
         return sp
 
+    def tn(self, i: int, B: int, what: str):
+        """(TNSpec, PackSpec) when stage i's `what` ('fprop' of a narrow ConvTranspose2d, 'dgrad' of a narrow Conv2d)
+        runs on the edge-layer kernel (vg_tnconv) instead of the gather-GEMM, else None.  VG_EDGE=0 turns it off."""
+        key = (i, B, "tn_" + what)
+        if key not in self._specs:
+            st, sp = self.stages[i], None
+            if os.environ.get("VG_EDGE", "1") != "0" and st.bn is None and not st.has_bias:
+                a = (B, st.hin, st.hin, st.cin, st.cout, st.k, st.s, st.p, self.dtype)
+                if st.kind == "convT" and what == "fprop" and st.act == VG_ACT_NONE:
+                    sp = G.convT_fprop_tn(*a)
+                elif st.kind == "conv" and what == "dgrad":
+                    sp = G.conv_dgrad_tn(*a)
+            self._specs[key] = sp
+        return self._specs[key]
+
     # ---- parameter handling ---------------------------------------------------------------------
     def params(self) -> List[torch.Tensor]:
         ps = []
@@ -233,6 +248,10 @@ class StackEngine:
                 _, pk = self.spec(i, 1, what)
                 ent[what] = torch.empty(pk.numel(), dtype=ops.TORCH_DT[self.dtype], device=dev)
                 descs.append(ops.pack_desc(pk, w, ent[what]))
+                if st.kind != "head" and self.tn(i, 1, what) is not None:      # edge-layer operand [(kh,kw,n)][C]
+                    _, tpk = self.tn(i, 1, what)
+                    ent["tn_" + what] = torch.empty(tpk.numel(), dtype=ops.TORCH_DT[self.dtype], device=dev)
+                    descs.append(ops.pack_desc(tpk, w, ent["tn_" + what]))
         self._packs, self._pack_ptrs = packs, ptr_key
         (self._pack_table, self._pack_max), self._pack_n = ops.pack_table(descs, dev), len(descs)
 
@@ -269,7 +288,7 @@ class StackEngine:
             self._specs[key] = ok
         return self._specs[key]
 
-    def forward(self, x: torch.Tensor, B: int, train: bool, keep: bool = True, groups: int = 1):
+    def forward(self, x: torch.Tensor, B: int, train: bool, keep: bool = True, groups: int = 1, tail=None):
         """x: NHWC activation of the first stage.  Returns (output, ctx).  For a 'head' last stage the
         output is p [B] (f32); otherwise the (activated) NHWC output of the last stage.
         groups > 1: x holds `groups` independent batches of B images (see can_group); BatchNorm statistics,
@@ -285,6 +304,24 @@ class StackEngine:
                 p = ops.dot_sigmoid_forward(a, packs[i]["fprop"], B, K, dt)
                 ctx.append({"x": a, "p": p})
                 a = p
+                continue
+            if self.tn(i, B, "fprop") is not None:
+                # edge layer (the Generator's last ConvTranspose2d): GEMM + col2im kernel; `tail` = dict(noise, sigma,
+                # out_noisy) fuses Tanh, the NCHW f32 image and the instance-noise add (vaegan_code.py:83,92) into it
+                tnsp, _ = self.tn(i, B, "fprop")
+                OC = G.padc(st.cout, dt)
+                if tail is not None and i == len(self.stages) - 1:
+                    Yn, img = ops.tnconv(tnsp, a, packs[i]["tn_fprop"], want_nhwc=tail.get("out_noisy") is not None,
+                                         want_nchw=True, act=VG_ACT_TANH, noise=tail.get("noise"),
+                                         sigma=tail.get("sigma", 0.0), out_nhwc=tail.get("out_noisy"), alg=st.alg(B, dt))
+                    out = img
+                    Yshape = (B, st.hout, st.hout, OC)
+                else:
+                    out, _ = ops.tnconv(tnsp, a, packs[i]["tn_fprop"], alg=st.alg(B, dt))
+                    Yshape = tuple(out.shape)
+                if keep:
+                    ctx.append({"x": a, "Y": None, "Yshape": Yshape, "coeffs": None, "rows": B * st.hout * st.hout, "OC": OC})
+                a = out
                 continue
             gg, pk = self.spec(i, B, "fprop")
             want_stats = st.bn is not None and train
@@ -333,13 +370,38 @@ class StackEngine:
                         out[id(p)] = i
         return out
 
+    @staticmethod
+    def run_deferred(deferred, device) -> None:
+        """Launch weight-gradient work collected by backward(defer=...) on the side stream, forked from the current
+        stream.  The caller joins with join_deferred() before anything reads the gradients."""
+        if not deferred:
+            return
+        side = side_stream(device)
+        side.wait_stream(torch.cuda.current_stream())
+        ops.set_ws_suffix(".side")
+        try:
+            with torch.cuda.stream(side):
+                for fn in deferred:
+                    fn()
+        finally:
+            ops.set_ws_suffix(None)
+
+    @staticmethod
+    def join_deferred(deferred, device) -> None:
+        if deferred:
+            torch.cuda.current_stream().wait_stream(side_stream(device))
+            deferred.clear()                  # the closures kept the operands alive until here
+
     def backward(self, ctxpack, dout: torch.Tensor, need_dx: bool, sink: GradSink, param_grads: bool = True,
-                 on_grads=None):
+                 on_grads=None, defer=None):
         """dout: gradient w.r.t. forward()'s output.  Returns the gradient w.r.t. the NHWC input (or None).
         param_grads=False skips every weight/bias/BN-parameter gradient (legal when the caller discards
         them, e.g. the generator-loss pass through the discriminator).
         on_grads(i): called right after every parameter gradient of stage i has been enqueued (stages run
-        last-to-first) -- the data-parallel trainer launches a gradient bucket's all-reduce from it."""
+        last-to-first) -- the data-parallel trainer launches a gradient bucket's all-reduce from it.
+        defer: a list -> the conv weight / bias gradient launches are NOT issued but appended to it as closures (the
+        data-gradient chain, which is the critical path, runs alone); the caller launches them with run_deferred()
+        beside later work and joins before the optimizer step."""
         ctx, B, train = ctxpack
         if not train:
             raise RuntimeError("backward through an eval-mode network is not supported (the reference never does it)")
@@ -363,7 +425,8 @@ class StackEngine:
                 dA = dx
                 continue
             Y, rows, OC = c["Y"], c["rows"], c["OC"]
-            dA = dA.view(Y.shape) if dA.shape != Y.shape else dA
+            yshape = c["Yshape"] if Y is None else Y.shape
+            dA = dA.view(yshape) if dA.shape != yshape else dA
             if st.bn is not None:
                 if param_grads:
                     gg_, acc_g = sink.get(st.bn.weight)
@@ -378,7 +441,9 @@ class StackEngine:
             else:
                 dY = dA                                     # no activation, or its backward was fused into the dgrad above
             masked = False
-            if param_grads:
+            if param_grads and defer is not None:
+                defer.append(lambda i=i, st=st, c=c, dY=dY, rows=rows, OC=OC: self._param_grads(i, st, c, dY, B, rows, OC, sink))
+            elif param_grads:
                 if side is None:
                     self._param_grads(i, st, c, dY, B, rows, OC, sink)
                 else:
@@ -388,7 +453,11 @@ class StackEngine:
                     held.append(dY)
                 if on_grads is not None and side is None:
                     on_grads(i)
-            if want_dx:
+            if want_dx and self.tn(i, B, "dgrad") is not None:
+                tnsp, _ = self.tn(i, B, "dgrad")            # image gradient below a narrow first Conv2d (edge layer)
+                dX, _ = ops.tnconv(tnsp, dY, packs[i]["tn_dgrad"], alg=st.alg(B, dt))
+                dA = dX.view(c["x"].shape)
+            elif want_dx:
                 ggd, _ = self.spec(i, B, "dgrad")
                 mask = None
                 if i > 0:

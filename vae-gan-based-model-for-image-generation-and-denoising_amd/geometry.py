@@ -156,6 +156,49 @@ def _tap_in_n(B, C, N_out, khw, dtype, s_n, s_c) -> Tuple[GGSpec, PackSpec]:
     return gg, pk
 
 
+# ------------------------------------------------------------------------------------------------
+# Narrow-N transposed form (vg_tnconv, csrc/edge_conv.hip): big[b][s*iy - p + kh][..][n] += small[b][iy][ix][:] . w[:][n][kh][kw]
+# as one GEMM per input pixel over the channels + col2im.  For the 3-channel image side of the networks.
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class TNSpec:
+    B: int; IH: int; IW: int; C: int; N: int; K: int; S: int; P: int; OH: int; OW: int; OC: int; Wpitch: int
+
+    def flops(self) -> int:
+        return 2 * self.B * self.IH * self.IW * self.C * self.N * self.K * self.K
+
+
+def tn_spec(B, h, w, C, N, k, s, p, dtype, s_n, s_c):
+    """-> (TNSpec, PackSpec) or None when vg_tnconv does not take the shape (the gather-GEMM form is used then).
+    s_n / s_c: element strides of the n / c index in the [c][n][k][k]-ordered weight."""
+    if dtype != BF16 or C not in (32, 64) or N > 4 or k * k * N > 64 or (k, s) not in ((3, 1), (4, 2)):
+        return None
+    npix = 512 if (k * k * N + 15) // 16 <= 2 else 256     # input pixels per workgroup tile (csrc/edge_conv.hip: tn_plan)
+    if w % 16 != 0 or w > npix or h != w:
+        return None
+    OH, OW = convT_out(h, k, s, p), convT_out(w, k, s, p)
+    rows_needed = (s - 1 + k - 1) // s + 1                 # input rows behind the smallest output row block
+    if rows_needed * w > npix:
+        return None
+    Kp = kpad(C, dtype)
+    tn = TNSpec(B=B, IH=h, IW=w, C=C, N=N, K=k, S=s, P=p, OH=OH, OW=OW, OC=padc(N, dtype), Wpitch=Kp)
+    pk = PackSpec(nphase=1, N=k * k * N, C=C, IC=C, TH=1, TW=1, Kp=Kp, s_n=s_n, s_c=s_c, KW=1,
+                  kh0=[0], kw0=[0], kh_step=1, kw_step=1, tap_in_n=1, KHW=k * k)
+    return tn, pk
+
+
+def convT_fprop_tn(B, H, W, Cin, Cout, k, s, p, dtype):
+    return tn_spec(B, H, W, Cin, Cout, k, s, p, dtype, s_n=k * k, s_c=Cout * k * k)
+
+
+def conv_dgrad_tn(B, H, W, Cin, Cout, k, s, p, dtype):
+    """dx [B,H,W,Cin] from dy [B,OH,OW,Cout] (OH = conv_out(H)); only when the transposed map covers H exactly."""
+    OH, OW = conv_out(H, k, s, p), conv_out(W, k, s, p)
+    if convT_out(OH, k, s, p) != H or convT_out(OW, k, s, p) != W:
+        return None
+    return tn_spec(B, OH, OW, Cout, Cin, k, s, p, dtype, s_n=k * k, s_c=Cin * k * k)
+
+
 # ---- nn.Conv2d(Cin, Cout, k, s, p): weight [Cout][Cin][k][k] ---------------------------------------
 def conv_fprop(B, H, W, Cin, Cout, k, s, p, dtype):
     return _direct(B, H, W, Cin, Cout, k, s, p, dtype, s_n=Cin * k * k, s_c=k * k)

@@ -304,17 +304,27 @@ class Generator(_EngineNet):
         assert h == img_size
         self._engine = StackEngine(stages, self._dt, nz)
 
-    def engine_forward(self, z_nhwc, B, keep=True):
-        """z_nhwc: [B,1,1,ZP] engine dtype -> (pre-tanh NHWC image, ctx)."""
-        return self._engine.forward(z_nhwc, B, self.training, keep)
+    def engine_forward(self, z_nhwc, B, keep=True, tail=None):
+        """z_nhwc: [B,1,1,ZP] engine dtype -> (pre-tanh NHWC image, ctx).
+        tail = dict(noise=..., sigma=..., out_noisy=...) (see fused_tail): -> (tanh image NCHW f32, ctx) with Tanh, the
+        layout change and the instance-noise add done by the last layer's kernel."""
+        return self._engine.forward(z_nhwc, B, self.training, keep, tail=tail)
+
+    def fused_tail(self, B) -> bool:
+        """True when the last ConvTranspose2d runs on the edge-layer kernel, which can apply Tanh and emit the NCHW
+        image (+ the noisy NHWC copy for the Discriminator) itself."""
+        return self._engine.tn(len(self._engine.stages) - 1, B, "fprop") is not None
 
     def _forward_impl(self, z, keep):
         if z.dim() != 4 or z.shape[1] != self.nz or z.shape[2] != 1 or z.shape[3] != 1:
             raise RuntimeError(f"Generator expects z of shape [B,{self.nz},1,1], got {tuple(z.shape)}")
         B = z.shape[0]
         zh = ops.nchw_to_nhwc(z.contiguous(), G.padc(self.nz, self._dt), self._dt)
-        pre, saved = self.engine_forward(zh, B, keep)
-        img = ops.nhwc_to_nchw(pre, self.nc, self._dt, apply_tanh=True)
+        if self.fused_tail(B):
+            img, saved = self.engine_forward(zh, B, keep, tail={})
+        else:
+            pre, saved = self.engine_forward(zh, B, keep)
+            img = ops.nhwc_to_nchw(pre, self.nc, self._dt, apply_tanh=True)
         return img, ((saved, img) if keep else None)
 
     def _backward_impl(self, saved, douts, need_dx, sink, param_grads=True):

@@ -9,7 +9,7 @@ from ctypes import byref, c_int
 import torch
 
 from . import _lib as L
-from .geometry import BF16, F32, GGSpec, PackSpec, WGSpec, esize
+from .geometry import BF16, F32, GGSpec, PackSpec, TNSpec, WGSpec, esize
 
 TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16}
 
@@ -48,13 +48,19 @@ class _Workspace:
 
 
 WS = _Workspace()
+_WS_SUFFIX = None          # set by engine.run_deferred while launching on the side stream
+
+
+def set_ws_suffix(sfx) -> None:
+    global _WS_SUFFIX
+    _WS_SUFFIX = sfx
 
 
 class KernelTimer:
     """Live timing of the GEMM-class launches (bench.py's roofline leg): the library brackets each kernel with a
     HIP start/stop event pair on its launch stream (vg_timing_*); this object only adds up the algorithmic
     FLOP / bytes of the same launches.  Off by default."""
-    FAMILIES = {"gather_gemm": 0, "wgrad": 1}
+    FAMILIES = {"gather_gemm": 0, "wgrad": 1, "edge": 2}
 
     def __init__(self):
         self.acc = {k: dict(flops=0, bytes=0) for k in self.FAMILIES}
@@ -143,6 +149,12 @@ class NoiseStream:
 
 
 _NOISE = {}
+
+
+def reset_noise() -> None:
+    """Forget the per-device default noise streams: the next draw starts a fresh stream at iteration 0, keyed by
+    torch's current device seed (utils.configure_seed calls this)."""
+    _NOISE.clear()
 
 
 def default_noise(device) -> NoiseStream:
@@ -254,11 +266,45 @@ def gather_gemm(g: GGSpec, X: torch.Tensor, Wp: torch.Tensor, dtype: int, bias: 
     if wsb > 0:
         ws = WS.get("splitk", wsb, X.device)
         d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * 4
-    tok = TIMER.begin("gather_gemm", *(alg or (g.flops(), 0))) if TIMER is not None else None
+    tok = None
+    if TIMER is not None:
+        fam = "edge" if lib.vg_gather_gemm_family(byref(d), dtype) == 2 else "gather_gemm"
+        tok = TIMER.begin(fam, *(alg or (g.flops(), 0)))
     L.check(lib.vg_gather_gemm(byref(d), dtype, L.stream_ptr()), "vg_gather_gemm")
     if tok is not None:
         TIMER.end(tok)
     return Y, stats, nparts
+
+
+def tnconv(tn: TNSpec, X: torch.Tensor, Wp: torch.Tensor, want_nhwc: bool = True, want_nchw: bool = False,
+           act: int = 0, noise=None, sigma: float = 0.0, out_nhwc: torch.Tensor = None, alg=None):
+    """Narrow-N transposed convolution (vg_tnconv) -> (Y NHWC bf16 [B,OH,OW,OC] or None, Y NCHW f32 or None).
+    noise: None, an NCHW f32 tensor [B,N,OH,OW] or a NoiseDraw; with noise, Y = act(.) + sigma*noise."""
+    rng = isinstance(noise, NoiseDraw)
+    _need_cuda(X, Wp, None if rng else noise, out_nhwc)
+    if X.dtype != torch.bfloat16 or Wp.dtype != torch.bfloat16:
+        raise RuntimeError("tnconv: bf16 operands only")
+    if X.numel() != tn.B * tn.IH * tn.IW * tn.C or Wp.numel() != tn.K * tn.K * tn.N * tn.Wpitch:
+        raise RuntimeError("tnconv: operand size mismatch")
+    Y = None
+    if want_nhwc:
+        Y = out_nhwc if out_nhwc is not None else torch.empty(tn.B, tn.OH, tn.OW, tn.OC, dtype=torch.bfloat16, device=X.device)
+        if Y.numel() != tn.B * tn.OH * tn.OW * tn.OC:
+            raise RuntimeError("tnconv: output size mismatch")
+    Yc = torch.empty(tn.B, tn.N, tn.OH, tn.OW, dtype=torch.float32, device=X.device) if want_nchw else None
+    if noise is not None and not rng and noise.numel() != tn.B * tn.N * tn.OH * tn.OW:
+        raise RuntimeError("tnconv: noise tensor must be [B,N,OH,OW]")
+    d = L.TNDesc(X=X.data_ptr(), Wp=Wp.data_ptr(), Y=0 if Y is None else Y.data_ptr(),
+                 Y_nchw=0 if Yc is None else Yc.data_ptr(),
+                 eps=noise.data_ptr() if (noise is not None and not rng) else 0,
+                 rng=noise.state.data_ptr() if rng else 0, draw=noise.draw if rng else 0, sigma=sigma,
+                 B=tn.B, IH=tn.IH, IW=tn.IW, C=tn.C, N=tn.N, K=tn.K, S=tn.S, P=tn.P, OH=tn.OH, OW=tn.OW, OC=tn.OC,
+                 Wpitch=tn.Wpitch, act=act)
+    tok = TIMER.begin("edge", *(alg or (tn.flops(), 0))) if TIMER is not None else None
+    L.check(L.load().vg_tnconv(byref(d), L.stream_ptr()), "vg_tnconv")
+    if tok is not None:
+        TIMER.end(tok)
+    return Y, Yc
 
 
 def wgrad(wg: WGSpec, P: torch.Tensor, Q: torch.Tensor, dW: torch.Tensor, accumulate: bool, dtype: int,
@@ -276,7 +322,8 @@ def wgrad(wg: WGSpec, P: torch.Tensor, Q: torch.Tensor, dW: torch.Tensor, accumu
     nbytes = lib.vg_wgrad_ws_bytes(byref(d), dtype)
     if nbytes < 0:
         L.check(int(nbytes), "vg_wgrad_ws_bytes")
-    ws = WS.get("wgrad", nbytes, P.device)
+    # the slab workspace is shared by all launches of one stream; work forked onto another stream gets its own
+    ws = WS.get("wgrad" if _WS_SUFFIX is None else "wgrad" + _WS_SUFFIX, nbytes, P.device)
     d.ws = ws.data_ptr()
     d.ws_bytes = ws.numel() * 4
     tok = TIMER.begin("wgrad", *(alg or (0, 0))) if TIMER is not None else None
@@ -400,7 +447,7 @@ def act_backward(x, dy, act, slope, dtype):
 
 def bias_grad(dy, rows, C, NC, dbias, accumulate, dtype):
     cap = 1024
-    ws = WS.get("biasgrad", cap * 2 * C * 4, dy.device)      # own buffer: may run on the side stream
+    ws = WS.get("biasgrad" if _WS_SUFFIX is None else "biasgrad" + _WS_SUFFIX, cap * 2 * C * 4, dy.device)
     L.check(L.load().vg_bias_grad(dy.data_ptr(), rows, C, NC, dbias.data_ptr(), 1 if accumulate else 0,
                                   ws.data_ptr(), cap, dtype, L.stream_ptr()), "vg_bias_grad")
 

@@ -44,6 +44,12 @@ class VAEGANTrainer:
             raise ValueError("encoder / decoder / discriminator must share one engine dtype")
         self.dt = dts.pop()
         self.latent = encoder.latent_dim
+        # Opt-in experiment (VG_OVERLAP_E=1): run the Generator's weight gradients beside the Encoder's backward on a
+        # second stream.  MEASURED SLOWER on MI355X (S=64, B=128, graph replay, interleaved A/B: 3.156 vs 3.079 ms):
+        # like the per-layer side-stream weight gradients of round 1, concurrent grids cost more in lost L2/LDS
+        # residency and queueing than the latency-bound Encoder chain leaves idle.
+        import os
+        self.overlap_encoder_backward = os.environ.get("VG_OVERLAP_E", "0") == "1"
         self.losses = None
         self.noise = None               # ops.NoiseStream for the in-kernel randn_like draws (created on first use)
         self._bucket_plans = {}
@@ -152,20 +158,23 @@ class VAEGANTrainer:
         mulv, ctxE = E.engine_forward(real)
         ZP = G.padc(Gn.nz, dt)
         z, lvc = ops.reparam_forward(mulv, eps_z, L, ZP, dt)
-        pre, ctxG = Gn.engine_forward(z, B)
-
         # ---- instance noise, drawn once per step (:91-92); produced directly in the layout D reads.  Both noisy
         # batches live in one [2B] buffer so that a Discriminator iteration can run real+fake as ONE grouped pass
         # (per-group BatchNorm statistics, running stats updated real-then-fake as the reference's two calls do).
         CP = G.padc(D.nc, dt)
         both = ops.empty_act((2 * B, real.shape[2], real.shape[3], CP), dt, dev)
         real_noisy = ops.nchw_to_nhwc(real, CP, dt, eps=eps_real, sigma=self.sigma, out=both[:B])
-        if Gn.nc == D.nc and pre.shape[-1] == CP:
-            recon = ops.nhwc_tanh_to_nchw_noisy(pre, Gn.nc, eps_recon, self.sigma, both[B:], dt)     # :83 and :92 in one pass
-            recon_noisy = both[B:]
+        recon_noisy = both[B:]
+        if Gn.nc == D.nc and G.padc(Gn.nc, dt) == CP and Gn.fused_tail(B):
+            # the last ConvTranspose2d's kernel applies Tanh and writes the NCHW image AND image + sigma*eps in D's layout
+            recon, ctxG = Gn.engine_forward(z, B, tail=dict(noise=eps_recon, sigma=self.sigma, out_noisy=recon_noisy))
         else:
-            recon = ops.nhwc_to_nchw(pre, Gn.nc, dt, apply_tanh=True)
-            recon_noisy = ops.nchw_to_nhwc(recon, CP, dt, eps=eps_recon, sigma=self.sigma, out=both[B:])
+            pre, ctxG = Gn.engine_forward(z, B)
+            if Gn.nc == D.nc and pre.shape[-1] == CP:
+                recon = ops.nhwc_tanh_to_nchw_noisy(pre, Gn.nc, eps_recon, self.sigma, recon_noisy, dt)   # :83 and :92 in one pass
+            else:
+                recon = ops.nhwc_to_nchw(pre, Gn.nc, dt, apply_tanh=True)
+                ops.nchw_to_nhwc(recon, CP, dt, eps=eps_recon, sigma=self.sigma, out=recon_noisy)
         grouped = self.group_d_passes and D._engine.can_group(B, 2, both)
 
         # ---- Discriminator updates (:95-105) ----
@@ -200,11 +209,16 @@ class VAEGANTrainer:
         d_noisy = D._engine.backward(c_adv, dp_adv, True, sink, param_grads=not self.elide_dead_grads)
         # d total / d recon = d MSE + d adv through the instance-noise add (:92), then through tanh: one pass
         d_pre = ops.nchw_grad_add_to_nhwc(d_recon, d_noisy, recon, G.padc(Gn.nc, dt), dt)
-        dz = Gn._engine.backward(ctxG, d_pre, True, sink, on_grads=self._grad_hook(self.opt_G, Gn))
+        # (opt-in, see __init__) the Generator's weight gradients held back and launched on a second stream beside the
+        # Encoder's backward
+        deferred = [] if (self.reducer is None and self.overlap_encoder_backward) else None
+        dz = Gn._engine.backward(ctxG, d_pre, True, sink, on_grads=self._grad_hook(self.opt_G, Gn), defer=deferred)
         self._finish_reduce(self.opt_G, Gn, wait=False)       # G's last bucket overlaps the encoder's backward
+        Gn._engine.run_deferred(deferred, dev)
         kl_w = self.alpha_kl * min(1.0, epoch / 50)                                            # :117
         dmulv = ops.reparam_kl_backward(mulv, lvc, eps_z, dz, kl_w / B, L, dt)
         E._engine.backward(ctxE, dmulv.view(B, 1, 1, -1), False, sink, on_grads=self._grad_hook(self.opt_E, E))
+        Gn._engine.join_deferred(deferred, dev)
         self._finish_reduce(self.opt_E, E, also_wait=(self.opt_G,))
         self.opt_E.step()
         self.opt_G.step()

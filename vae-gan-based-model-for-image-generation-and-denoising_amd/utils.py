@@ -15,3 +15,6 @@ def configure_seed(seed):
         torch.cuda.manual_seed(seed)
         torch.backends.cudnn.deterministic = True     # MIOpen is never used by this engine; kept for parity
         torch.backends.cudnn.benchmark = False
+    # the HIP noise streams behind the non-injected randn_like draws restart with the seed, like torch's generator
+    from . import ops
+    ops.reset_noise()
