@@ -30,7 +30,7 @@ import torch.distributed as dist  # noqa: E402
 
 # ALGORITHMIC conv/convT/linear FLOP per image per step (fwd + wgrad + dgrad, D x5)
 ALG_GFLOP_PER_IMAGE = {64: 6.45, 128: 8.77, 256: 12.561}
-PEAK = {"fp32": 157.3, "bf16": 2500.0}          # dense MFMA TFLOP/s, MI355X_MICROARCH.md
+PEAK = {"fp32": 157.3, "bf16": 2500.0, "fp8": 5000.0}          # dense MFMA TFLOP/s, MI355X_MICROARCH.md (fp8: block-scaled K=128 forms)
 # HBM-side bytes per gather-GEMM launch from the rocprofv3 PMC passes committed under profiles/ (separate
 # --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command; FETCH_SIZE doubled per the gfx950 correction of
 # MI355X_MICROARCH.md section HBM, counters in KiB): measured offline, NOT re-measured by this run.
@@ -195,8 +195,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--size", type=int, default=64)
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch")
-    ap.add_argument("--dtype", default=os.environ.get("VAEGAN_BENCH_DTYPE", "bf16"), choices=["fp32", "bf16"],
-                    help="bf16 = BASELINE configs[1] (bf16 storage, f32 accumulate, fp32 master weights); fp32 = parity path")
+    ap.add_argument("--dtype", default=os.environ.get("VAEGAN_BENCH_DTYPE", "bf16"), choices=["fp32", "bf16", "fp8"],
+                    help="bf16 = BASELINE configs[1] (bf16 storage, f32 accumulate, fp32 master weights); fp32 = parity path; "
+                         "fp8 = BASELINE configs[4] (e4m3 operands for the forward GEMMs of the wide conv layers on the "
+                         "block-scaled MFMA, everything else as bf16; quoted at --size 256 --batch 32; roofline run, no parity claim)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-paths", action="store_true",
                     help="skip the secondary legs (fp32 parity path, drop-in autograd path) reported beside the main number")
@@ -323,8 +325,8 @@ def main():
     ach = gg["flops"] / (gg["ms"] * 1e-3) / 1e12
     traffic, traffic_src = pmc_traffic(args.dtype)
     roofline = {"bound": "mfma", "kernel": "gg_kernel (gather-GEMM: conv/convT/linear fprop + dgrad)",
-                "achieved": round(ach, 2), "peak": PEAK[args.dtype], "unit": "TFLOP/s",
-                "frac": round(ach / PEAK[args.dtype], 4),
+                "achieved": round(ach, 2), "peak": PEAK["bf16" if args.dtype == "fp8" else args.dtype], "unit": "TFLOP/s",
+                "frac": round(ach / PEAK["bf16" if args.dtype == "fp8" else args.dtype], 4),
                 # HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/), not re-measured here
                 "traffic": traffic if (S, B) == (64, 128) else None,
                 "traffic_source": (f"{traffic_src}: separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of this "
@@ -356,7 +358,7 @@ def main():
     out = {"metric": "images/sec/GPU VAE-GAN train step", "value": round(value, 1), "unit": "images/sec",
            "per_gpu": round(value / world, 1), "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": {"fp32": "f32", "bf16": "bf16"}[args.dtype], "data": "synthetic",
+           "dtype": {"fp32": "f32", "bf16": "bf16", "fp8": "fp8(e4m3 fprop)+bf16"}[args.dtype], "data": "synthetic",
            "config": {"workload": f"CelebA-shaped {S}x{S} VAE-GAN full train step (E+G+5xD fwd, all bwd, 4 Adam), "
                                   f"batch {B}/GPU, global batch {B * world}", "img_size": S, "per_gpu_batch": B,
                       "global_batch": B * world, "parallelism": f"dp{world}", "epoch_kl_weight": 0.1,
@@ -365,6 +367,14 @@ def main():
            "roofline": roofline}
     if roofline_edge is not None:
         out["roofline_edge"] = roofline_edge
+    f8 = fam.get("gather_gemm_fp8", dict(launches=0, ms=0.0, flops=0, bytes=0))
+    if f8["launches"]:
+        a8 = f8["flops"] / (f8["ms"] * 1e-3) / 1e12
+        out["roofline_fp8"] = {"bound": "mfma", "kernel": "gg_kernel<fp8> (conv / convT fprop on v_mfma_scale_f32_16x16x128_f8f6f4, e4m3)",
+                               "achieved": round(a8, 2), "peak": PEAK["fp8"], "unit": "TFLOP/s", "frac": round(a8 / PEAK["fp8"], 4),
+                               "traffic": None, "launches_per_step": f8["launches"] // args.steps,
+                               "avg_launch_us": round(f8["ms"] * 1e3 / f8["launches"], 2),
+                               "share_of_step": round(f8["ms"] / args.steps / ms, 3)}
     if world == 1 and not multi and not args.no_extra_paths:
         del tr, e, g, d, oE, oG, oD
         out["parity_path"] = parity_path(V, S, B, dev, resident)

@@ -29,6 +29,12 @@ extern "C" {
 
 #define VG_F32  0
 #define VG_BF16 1
+#define VG_FP8  2   /* OCP e4m3fn operands, f32 accumulate, bf16 output: vg_gather_gemm fprop only (BASELINE configs[4],
+                     * a roofline run -- the reference has no fp8 semantics).  X: [..][IC] fp8, IC % 16 == 0; W: packed
+                     * [nphase][N][Kp] fp8 holding weight * 2^VG_FP8_WSHIFT (N(0, 0.02) weights would sit in e4m3's
+                     * subnormals); the block-scaled MFMA (v_mfma_scale_f32_16x16x128_f8f6f4) undoes the shift through
+                     * its E8M0 operand scale.  Y, bias, stats as for VG_BF16 (Y is bf16). */
+#define VG_FP8_WSHIFT 6
 
 #define VG_EINVAL   (-1)   /* bad shape / size / flag                                  */
 #define VG_EALIGN   (-2)   /* pointer or channel count violates the 16-byte contract   */
@@ -203,6 +209,10 @@ int vg_bn_eval_coeffs(const float* gamma, const float* beta, const float* runnin
 int vg_bn_act_forward(const void* x, void* y, const float* scale, const float* shift,
                       int64_t rows, int C, int act, float slope, int groups, int64_t gstride,
                       int dtype, void* stream);
+/* Same, additionally writing y8 = e4m3(y) (same [rows][C] layout, one byte per element; VG_BF16 only): the operand of
+ * the next layer's VG_FP8 forward GEMM, produced in the pass that produces the bf16 activation. */
+int vg_bn_act_forward_fp8(const void* x, void* y, void* y8, const float* scale, const float* shift, int64_t rows,
+                          int C, int act, float slope, int groups, int64_t gstride, int dtype, void* stream);
 /* Standalone per-channel statistics of an NHWC tensor (used when no conv epilogue produced them). */
 int vg_channel_stats(const void* x, int64_t rows, int C, float* stats, int stats_capacity,
                      int* nparts_out, int dtype, void* stream);
@@ -355,6 +365,9 @@ int vg_reparam_kl_backward_rng(const void* mulv, const float* lv_clamped, const 
                                int dtype, void* stream);
 /* hipMemsetAsync(p, 0, nbytes) on the stream: optimizer.zero_grad() (vaegan_code.py:103,131-132) over a flat buffer. */
 int vg_memset_zero(void* p, int64_t nbytes, void* stream);
+/* bf16 -> OCP e4m3fn, elementwise: y[i] = fp8(x[i] * 2^shift).  The fp8 copies of activations (shift 0) and of the
+ * packed bf16 GEMM operands (shift VG_FP8_WSHIFT) that VG_FP8 launches of vg_gather_gemm read.  n % 8 == 0. */
+int vg_cast_fp8(const void* x_bf16, void* y_fp8, int64_t n, int shift, void* stream);
 /* out = a + alpha*b (f32, n elements); used for gradient joins on NCHW images. */
 int vg_axpy(const float* a, const float* b, float alpha, float* out, int64_t n, void* stream);
 /* PSNR/SSIM support for the denoise path lives in vg_image_metrics. */

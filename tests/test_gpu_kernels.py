@@ -270,6 +270,43 @@ def test_edge_layer_kernel_rejects_what_it_does_not_take(ops):
         ops.tnconv(tn, x, torch.zeros(5, dtype=torch.bfloat16, device=DEV))
 
 
+def _e4m3(t):
+    """Round to OCP e4m3fn the way the kernels' operands are (torch's float8_e4m3fn cast: round to nearest even)."""
+    return t.float().to(torch.float8_e4m3fn).double()
+
+
+@pytest.mark.parametrize("kind,cin,cout,h,B", [("conv", 64, 128, 16, 3), ("convT", 128, 64, 8, 3), ("conv", 16, 32, 24, 2),
+                                               ("convT", 32, 16, 12, 5)])
+def test_fp8_gather_gemm_vs_torch_on_e4m3_operands(ops, kind, cin, cout, h, B):
+    """VG_FP8 launches of vg_gather_gemm (block-scaled v_mfma_scale_f32_16x16x128_f8f6f4, BASELINE configs[4]):
+    exact f32 accumulation of e4m3 x e4m3 products, so against torch's convolution in fp64 on the SAME e4m3-rounded
+    operands only the bf16 rounding of the output remains.  Weights are stored * 2^6 and un-scaled by the MFMA's E8M0
+    operand.  k4 s2 p1 conv and transposed conv (4 sub-pixel phases), BatchNorm partial sums in the epilogue."""
+    g = torch.Generator().manual_seed(cin + cout + h)
+    x = torch.randn(B, cin, h, h, generator=g)
+    if kind == "conv":
+        w = torch.randn(cout, cin, 4, 4, generator=g) * 0.02
+        gg, pk = G.conv_fprop(B, h, h, cin, cout, 4, 2, 1, G.BF16)
+    else:
+        w = torch.randn(cin, cout, 4, 4, generator=g) * 0.02
+        gg, pk = G.convT_fprop(B, h, h, cin, cout, 4, 2, 1, G.BF16)
+    assert gg.Kp % 64 == 0 and gg.IC % 16 == 0
+    xb = _dev(to_nhwc(x, gg.IC), G.BF16, ops)
+    wp = ops.pack_weights(pk, w.to(DEV), G.BF16)
+    x8, w8 = ops.cast_fp8(xb), ops.cast_fp8(wp, 6)
+    Y, stats, nparts = ops.gather_gemm(gg, x8, w8, G.FP8, want_stats=True)
+    assert Y.dtype == torch.bfloat16
+    xq = _e4m3(_q(x, G.BF16))
+    wq = _e4m3(_q(w, G.BF16) * 64) / 64
+    ref = F.conv2d(xq, wq, stride=2, padding=1) if kind == "conv" else F.conv_transpose2d(xq, wq, stride=2, padding=1)
+    got = from_nhwc(Y.double().cpu(), cout)
+    close(got, _q(ref, G.BF16), G.BF16, bf16=(1e-2, 4e-3))
+    # BatchNorm partial sums of the epilogue: column sums of the f32 accumulators (before the bf16 rounding)
+    st = stats[:nparts * 2 * gg.N].view(nparts, 2, gg.N).double().cpu().sum(0)
+    torch.testing.assert_close(st[0], ref.sum((0, 2, 3)), rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(st[1], (ref * ref).sum((0, 2, 3)), rtol=1e-4, atol=1e-3)
+
+
 def test_in_kernel_noise_equals_materialised_draws_and_is_standard_normal(ops):
     """vg_*_rng (the three randn_like draws of vaegan_code.py:77,91,92 generated inside the consuming kernels) against
     the same kernels fed with vg_randn's materialisation of the same (seed, iteration, draw): bitwise.  Plus the

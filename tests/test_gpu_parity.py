@@ -400,6 +400,29 @@ def _deep_clone(x):
     return x
 
 
+def test_fp8_forward_engine_tracks_the_bf16_engine():
+    """dtype='fp8' (BASELINE configs[4]: e4m3 operands for the forward GEMMs of the wide conv layers, f32 accumulate;
+    backward, storage and master weights as the bf16 engine).  The reference has NO fp8 semantics -- this is a roofline
+    configuration without a parity claim -- so the check is statistical: first-iteration losses within 10 % of the
+    bf16 engine's on the same inputs (e4m3 carries 3 mantissa bits), everything finite, and the forward GEMMs of the
+    eligible layers did run on the fp8 kernel."""
+    S, B = 64, 16
+    real, ez, er, ec = (t.to(DEV) for t in make_inputs(B, S, 7000 + S))
+    out = {}
+    for dtype in ("bf16", "fp8"):
+        e, g, d, tr = build(S, dtype=dtype)
+        out[dtype] = tr.loss_dict(tr.train_step(real, 60, ez, er, ec), 60)
+        if dtype == "fp8":
+            assert [g._engine.fp8_ok(i) for i in range(6)] == [False, True, True, True, True, False]   # G0 is a plain GEMM, G5 an edge layer
+            assert [d._engine.fp8_ok(i) for i in range(4)] == [False, True, True, True]                  # D0 reads the 3-channel image
+            assert e._engine.fp8_ok(0) is False and e._engine.fp8_ok(1) is True
+            for p in list(e.parameters()) + list(g.parameters()) + list(d.parameters()):
+                assert p.dtype == torch.float32 and bool(torch.isfinite(p).all())
+    for n in V.LOSS_NAMES:
+        assert rel(out["fp8"][n], out["bf16"][n]) <= 0.10, f"fp8 {n}: {out['fp8'][n]} vs bf16 {out['bf16'][n]}"
+    print("fp8 vs bf16 first-iteration losses:", {n: f"{rel(out['fp8'][n], out['bf16'][n]):.1e}" for n in V.LOSS_NAMES})
+
+
 def test_grouped_discriminator_pass_equals_separate_passes():
     """One grouped 2B-row pass per D iteration (per-group BatchNorm statistics) vs the reference's two calls."""
     outs = []

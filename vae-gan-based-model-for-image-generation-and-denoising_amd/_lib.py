@@ -12,7 +12,8 @@ from ctypes import (POINTER, Structure, byref, c_char_p, c_double, c_float, c_in
 
 import torch  # noqa: F401  (must be loaded before the HIP library, see module docstring)
 
-VG_F32, VG_BF16 = 0, 1
+VG_F32, VG_BF16, VG_FP8 = 0, 1, 2
+VG_FP8_WSHIFT = 6
 VG_ACT_NONE, VG_ACT_RELU, VG_ACT_LRELU, VG_ACT_TANH = 0, 1, 2, 3
 VG_MAX_PHASE = 4
 ABI_VERSION = 3
@@ -92,6 +93,7 @@ SIGNATURES = {
     "vg_bn_backward_finalize_sums": (c_int, [_P, _P, _I, _L, _P, _P, _P, _P, _I, _P, _P]),
     "vg_bn_eval_coeffs": (c_int, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),
     "vg_bn_act_forward": (c_int, [_P, _P, _P, _P, _L, _I, _I, _F, _I, _L, _I, _P]),
+    "vg_bn_act_forward_fp8": (c_int, [_P, _P, _P, _P, _P, _L, _I, _I, _F, _I, _L, _I, _P]),
     "vg_channel_stats": (c_int, [_P, _L, _I, _P, _I, POINTER(c_int), _I, _P]),
     "vg_bn_act_backward_reduce": (c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _P, _I, POINTER(c_int), _I, _L,
                                           _I, _P]),
@@ -126,6 +128,7 @@ SIGNATURES = {
     "vg_reparam_forward_rng": (c_int, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
     "vg_reparam_kl_backward_rng": (c_int, [_P, _P, _P, _I, _P, _F, _P, _I, _I, _I, _I, _I, _P]),
     "vg_memset_zero": (c_int, [_P, _L, _P]),
+    "vg_cast_fp8": (c_int, [_P, _P, _L, _I, _P]),
     "vg_tnconv_supported": (c_int, [POINTER(TNDesc)]),
     "vg_tnconv": (c_int, [POINTER(TNDesc), _P]),
 }

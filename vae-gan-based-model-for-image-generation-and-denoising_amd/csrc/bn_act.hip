@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const void* __restrict_
                                                          const float* __restrict__ scale,
                                                          const float* __restrict__ shift, int64_t nvec, int cols,
                                                          int act, float slope, int64_t nvec_per_group,
-                                                         int64_t gstride) {
+                                                         int64_t gstride, uint32_t* __restrict__ y8) {
     auto one = [&](int64_t i, float4 v) {
         const int c4 = (int)(i % cols) * 4;
         if (scale) {
@@ -319,6 +319,11 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const void* __restrict_
         v.x = act_fwd(v.x, act, slope); v.y = act_fwd(v.y, act, slope);
         v.z = act_fwd(v.z, act, slope); v.w = act_fwd(v.w, act, slope);
         store4<DT>(y, i * 4, v);
+        if (y8) {                   // e4m3 twin of the activated tensor for an fp8 forward GEMM (same NHWC layout)
+            int w = __builtin_amdgcn_cvt_pk_fp8_f32(v.x, v.y, 0, false);
+            w = __builtin_amdgcn_cvt_pk_fp8_f32(v.z, v.w, w, true);
+            y8[i] = (uint32_t)w;
+        }
     };
     // four vectors in flight per thread (the grid is capped: big tensors give each thread several iterations)
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -529,20 +534,29 @@ extern "C" int vg_bn_eval_coeffs(const float* gamma, const float* beta, const fl
     return VG_LAUNCH_RC();
 }
 
+extern "C" int vg_bn_act_forward_fp8(const void* x, void* y, void* y8, const float* scale, const float* shift, int64_t rows,
+                                     int C, int act, float slope, int groups, int64_t gstride, int dtype, void* stream);
+
 extern "C" int vg_bn_act_forward(const void* x, void* y, const float* scale, const float* shift, int64_t rows, int C,
                                  int act, float slope, int groups, int64_t gstride, int dtype, void* stream) {
+    return vg_bn_act_forward_fp8(x, y, nullptr, scale, shift, rows, C, act, slope, groups, gstride, dtype, stream);
+}
+
+extern "C" int vg_bn_act_forward_fp8(const void* x, void* y, void* y8, const float* scale, const float* shift, int64_t rows,
+                                     int C, int act, float slope, int groups, int64_t gstride, int dtype, void* stream) {
     int rc = check_rows_c(x, rows, C, dtype);
     if (rc) return rc;
     VG_CHECK_ARG(y != nullptr && (scale == nullptr) == (shift == nullptr), VG_EINVAL);
     VG_CHECK_ARG(groups >= 1 && rows % groups == 0, VG_EINVAL);
+    VG_CHECK_ARG(y8 == nullptr || (dtype == VG_BF16 && (reinterpret_cast<uintptr_t>(y8) & 3u) == 0), VG_EINVAL);
     const int64_t nvec = rows * C / 4;
     const int64_t nvg = nvec / groups;
     if (dtype == VG_F32)
         hipLaunchKernelGGL(bn_act_fwd_kernel<VG_F32>, dim3(ew_blocks(nvec)), dim3(256), 0, vg_stream(stream), x, y,
-                           scale, shift, nvec, C / 4, act, slope, nvg, gstride);
+                           scale, shift, nvec, C / 4, act, slope, nvg, gstride, (uint32_t*)nullptr);
     else
         hipLaunchKernelGGL(bn_act_fwd_kernel<VG_BF16>, dim3(ew_blocks(nvec)), dim3(256), 0, vg_stream(stream), x, y,
-                           scale, shift, nvec, C / 4, act, slope, nvg, gstride);
+                           scale, shift, nvec, C / 4, act, slope, nvg, gstride, reinterpret_cast<uint32_t*>(y8));
     return VG_LAUNCH_RC();
 }
 

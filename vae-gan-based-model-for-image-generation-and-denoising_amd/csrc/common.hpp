@@ -35,6 +35,16 @@ template <> struct ElemT<VG_BF16> {
     }
 };
 
+template <> struct ElemT<VG_FP8> {          // OCP e4m3fn (gfx950); storage only: vg_gather_gemm's VG_FP8 operands
+    typedef uint8_t type;
+    static constexpr int size = 1;
+    static constexpr int per16 = 16;
+    __device__ static __forceinline__ float to_f32(uint8_t v) { return __builtin_amdgcn_cvt_f32_fp8((int)v, 0); }
+    __device__ static __forceinline__ uint8_t from_f32(float v) {
+        return (uint8_t)(__builtin_amdgcn_cvt_pk_fp8_f32(v, 0.f, 0, false) & 0xff);
+    }
+};
+
 // load / store a run of 4 consecutive elements as floats (16 B for f32, 8 B for bf16)
 template <int DT> __device__ __forceinline__ float4 load4(const void* base, int64_t idx);
 template <> __device__ __forceinline__ float4 load4<VG_F32>(const void* base, int64_t idx) {
@@ -100,7 +110,7 @@ struct VgTiming {
     bool on = false;
     std::mutex mu;
     std::vector<hipEvent_t> pool;                                 // free events
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> rec[3];         // family 0: gather-GEMM, 1: wgrad, 2: edge layers (HBM-bound)
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> rec[4];         // family 0: gather-GEMM, 1: wgrad, 2: edge layers (HBM-bound), 3: fp8 gather-GEMM
 };
 VgTiming& vg_timing();
 

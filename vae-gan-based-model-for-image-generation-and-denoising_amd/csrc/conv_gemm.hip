@@ -96,12 +96,16 @@ __global__ __launch_bounds__(256) void gg_kernel(const vg_gg_desc d, const int k
     const int ksplit = SPLITK ? ksplit_arg : 1;        // compile-time 1 on the common path (keeps its registers lean)
     typedef ElemT<DT> E;
     constexpr int ESZ = E::size;
+    // output element: the operand type, except fp8 operands (VG_FP8), which produce bf16 like the bf16 engine
+    constexpr int DTO = (DT == VG_FP8) ? VG_BF16 : DT;
+    typedef ElemT<DTO> EO;
+    constexpr int ESZO = EO::size;
     constexpr int TM = BM / WM / 16;
     constexpr int TN = BN / WN / 16;
     constexpr int AP = BM / 64;                    // A row passes per chunk
     constexpr int BP = (BN + 63) / 64;             // B row passes per chunk
     // 64-byte K chunks per barrier (bf16 MFMAs are 16x shorter than f32 ones)
-    constexpr int KCH = DMA ? DmaRing<BM, BN>::KCH : ((DT == VG_BF16) ? 2 : 1);
+    constexpr int KCH = DMA ? DmaRing<BM, BN>::KCH : ((DT == VG_F32) ? 1 : 2);    // fp8: 2 chunks = the MFMA's K of 128
     constexpr int CHB = (BM + BN) * 64;            // bytes of one chunk image
     constexpr int STAGE = CHB * KCH;               // bytes per LDS buffer
     constexpr int NBUF = DMA ? DmaRing<BM, BN>::NBUF : 2;    // DMA path: LDS ring, NBUF-1 stages in flight
@@ -258,6 +262,47 @@ __global__ __launch_bounds__(256) void gg_kernel(const vg_gg_desc d, const int k
 #ifdef VG_ABLATE_COMPUTE
         return;
 #endif
+        if constexpr (DT == VG_FP8) {
+            // v_mfma_scale_f32_16x16x128_f8f6f4: lane (row|col = lane & 15, k group = lane >> 4) holds 32 e4m3 values.
+            // Any assignment of the 128 k indices to (lane group, byte) is valid as long as A and B use the same one
+            // (checked with exact integer data, tools/probes/mfma_fp8_probe.hip): lane group fg takes 16-byte unit fg
+            // of BOTH 64-byte chunks of the stage -- the fragment reads of the bf16 path, concatenated.
+            typedef __attribute__((ext_vector_type(8))) int v8i;
+            static_assert(DT != VG_FP8 || KCH % 2 == 0, "fp8: whole K=128 steps per stage");
+#pragma unroll
+            for (int c0 = 0; c0 < KCH; c0 += 2) {
+            u32x4 fa[2][TM], fb[2][TN];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const unsigned char* sa = smem + buf * STAGE + (c0 + c) * CHB;
+                const unsigned char* sb = sa + BM * 64;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int r = wm * (BM / WM) + i * 16 + fr;
+                    fa[c][i] = *reinterpret_cast<const u32x4*>(sa + r * 64 + ((fg ^ ((-(r >> 2)) & 3)) << 4));
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int r = wn * (BN / WN) + j * 16 + fr;
+                    fb[c][j] = *reinterpret_cast<const u32x4*>(sb + r * 64 + ((fg ^ ((-(r >> 2)) & 3)) << 4));
+                }
+            }
+            constexpr int SA = 127 * 0x01010101;                          // E8M0 1.0 for the activations
+            constexpr int SB = (127 - VG_FP8_WSHIFT) * 0x01010101;        // 2^-shift: weights are stored * 2^shift
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const v8i av = {(int)fa[0][i][0], (int)fa[0][i][1], (int)fa[0][i][2], (int)fa[0][i][3],
+                                (int)fa[1][i][0], (int)fa[1][i][1], (int)fa[1][i][2], (int)fa[1][i][3]};
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const v8i bv = {(int)fb[0][j][0], (int)fb[0][j][1], (int)fb[0][j][2], (int)fb[0][j][3],
+                                    (int)fb[1][j][0], (int)fb[1][j][1], (int)fb[1][j][2], (int)fb[1][j][3]};
+                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bv, acc[i][j], 0, 0, 0, SA, 0, SB);
+                }
+            }
+            }
+            return;
+        }
 #pragma unroll
         for (int c = 0; c < KCH; ++c) {
             const unsigned char* sa = smem + buf * STAGE + c * CHB;
@@ -289,7 +334,7 @@ __global__ __launch_bounds__(256) void gg_kernel(const vg_gg_desc d, const int k
                         for (int j = 0; j < TN; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(
                                 __uint_as_float(fa[i][kk]), __uint_as_float(fb[j][kk]), acc[i][j], 0, 0, 0);
-            } else {
+            } else if constexpr (DT == VG_BF16) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -546,13 +591,13 @@ __global__ __launch_bounds__(256) void gg_kernel(const vg_gg_desc d, const int k
     }
 
     // C tile staging: pitch padded by 16 B; the tile is written in NPASS row blocks when it exceeds the LDS buffers
-    constexpr int NPASS = (BM * (BN * ESZ + 16) <= NBUF * STAGE) ? 1 : WM;
+    constexpr int NPASS = (BM * (BN * ESZO + 16) <= NBUF * STAGE) ? 1 : WM;
     constexpr int PROWS = BM / NPASS;
-    constexpr int CPITCH = BN * ESZ + ((PROWS * (BN * ESZ + 16) <= NBUF * STAGE) ? 16 : 0);
+    constexpr int CPITCH = BN * ESZO + ((PROWS * (BN * ESZO + 16) <= NBUF * STAGE) ? 16 : 0);
     static_assert(PROWS * CPITCH <= NBUF * STAGE, "C tile pass does not fit in LDS");
-    constexpr int SEGS = BN * ESZ / 16;                // 16-byte segments per tile row
+    constexpr int SEGS = BN * ESZO / 16;                // 16-byte segments per tile row
     unsigned char* Yb = reinterpret_cast<unsigned char*>(d.Y);
-    const int oc_bytes = d.OC * ESZ;
+    const int oc_bytes = d.OC * ESZO;
 #pragma unroll
     for (int pass = 0; pass < NPASS; ++pass) {
         const bool mine = (NPASS == 1) || (wm == pass);
@@ -565,19 +610,19 @@ __global__ __launch_bounds__(256) void gg_kernel(const vg_gg_desc d, const int k
                     for (int r = 0; r < 4; ++r) {
                         const int row = wm * (BM / WM) + i * 16 + fg * 4 + r - pass * PROWS;
                         const int col = wn * (BN / WN) + j * 16 + fr;
-                        typename E::type* dst = reinterpret_cast<typename E::type*>(smem + row * CPITCH) + col;
-                        *dst = E::from_f32(acc[i][j][r]);
+                        typename EO::type* dst = reinterpret_cast<typename EO::type*>(smem + row * CPITCH) + col;
+                        *dst = EO::from_f32(acc[i][j][r]);
                     }
         }
         __syncthreads();
         for (int u = tid; u < PROWS * SEGS; u += 256) {
             const int row = u / SEGS, seg = u - row * SEGS;
             const int op = opix_tab[pass * PROWS + row];
-            const int cb = n0 * ESZ + seg * 16;        // byte offset of this segment inside the output pixel
+            const int cb = n0 * ESZO + seg * 16;        // byte offset of this segment inside the output pixel
             if (op >= 0 && cb < oc_bytes) {
                 u32x4 v = *reinterpret_cast<const u32x4*>(smem + row * CPITCH + seg * 16);
                 if (d.mask_x != nullptr)
-                    v = mask_segment<DT>(v, *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(d.mask_x) +
+                    v = mask_segment<DTO>(v, *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(d.mask_x) +
                                                                            (int64_t)op * oc_bytes + cb), d.mask_act, d.mask_slope);
                 *reinterpret_cast<u32x4*>(Yb + (int64_t)op * oc_bytes + cb) = v;
             }
@@ -649,11 +694,16 @@ inline int patch256_min() {
     return e ? atoi(e) : 256;               // 256 x 128 tiles where every CU gets at least one (step sweep: 128 / 192 / 256 / 384 -> 38.3 / 38.6 / 38.7 / 38.7k img/s)
 }
 
-inline TileCfg pick_tile(const vg_gg_desc* d, bool bf16 = false) {
+inline TileCfg pick_tile(const vg_gg_desc* d, bool bf16 = false, bool fp8 = false) {
     const int M = d->B * d->GH * d->GW;
     const int N = d->N;
     const int ph = d->nphase;
     const int need = min_wgs();
+    if (fp8) {                                                    // plain register-staged tiles only
+        if (N > 64 && tiles_of(M, N, 128, 128) * ph >= need) return {128, 128};
+        if (tiles_of(M, N, 128, 64) * ph >= need) return {128, 64};
+        return {64, 64};
+    }
     if (bf16 && narrowk_ok(d, VG_BF16)) return {NK_BM, N};       // 3-channel-input edge layers: ggn_kernel, all N per workgroup
     if (N <= 16) return {256, 16};
     if (N <= 32) return {128, 32};
@@ -671,8 +721,10 @@ inline TileCfg pick_tile(const vg_gg_desc* d, bool bf16 = false) {
 
 inline int validate(const vg_gg_desc* d, int dtype) {
     VG_CHECK_ARG(d != nullptr, VG_EINVAL);
-    VG_CHECK_ARG(dtype == VG_F32 || dtype == VG_BF16, VG_ENOSUP);
-    const int esz = dtype == VG_F32 ? 4 : 2;
+    VG_CHECK_ARG(dtype == VG_F32 || dtype == VG_BF16 || dtype == VG_FP8, VG_ENOSUP);
+    const int esz = dtype == VG_F32 ? 4 : (dtype == VG_BF16 ? 2 : 1);
+    const int eszo = dtype == VG_F32 ? 4 : 2;                  // fp8 operands write bf16
+    VG_CHECK_ARG(dtype != VG_FP8 || d->mask_x == nullptr, VG_ENOSUP);
     VG_CHECK_ARG(d->X && d->W && d->Y, VG_EINVAL);
     VG_CHECK_ARG(d->B > 0 && d->GH > 0 && d->GW > 0 && d->IH > 0 && d->IW > 0 && d->IC > 0, VG_EINVAL);
     VG_CHECK_ARG(d->N > 0 && d->OC >= d->N && d->OH > 0 && d->OW > 0, VG_EINVAL);
@@ -680,7 +732,7 @@ inline int validate(const vg_gg_desc* d, int dtype) {
     VG_CHECK_ARG((d->IC * esz) % 16 == 0, VG_EALIGN);
     VG_CHECK_ARG((d->Kp * esz) % 64 == 0 && d->Kp >= d->TH * d->TW * d->IC, VG_EALIGN);
     VG_CHECK_ARG(vg_aligned16(d->X) && vg_aligned16(d->W) && vg_aligned16(d->Y), VG_EALIGN);
-    VG_CHECK_ARG((d->OC * esz) % 16 == 0, VG_EALIGN);
+    VG_CHECK_ARG((d->OC * eszo) % 16 == 0, VG_EALIGN);
     VG_CHECK_ARG(d->act == VG_ACT_NONE || ((d->act == VG_ACT_RELU || d->act == VG_ACT_LRELU) && d->stats == nullptr), VG_EINVAL);
     VG_CHECK_ARG(d->mask_x == nullptr || (vg_aligned16(d->mask_x) && (d->mask_act == VG_ACT_RELU || d->mask_act == VG_ACT_LRELU)), VG_EINVAL);
     VG_CHECK_ARG((int64_t)d->B * d->GH * d->GW < (1ll << 31), VG_EINVAL);
@@ -696,7 +748,7 @@ inline SplitK plan_splitk(const vg_gg_desc* d, int dtype, TileCfg t) {
     SplitK r{1, 0, 0};
     const int M = d->B * d->GH * d->GW;
     const bool flat = d->nphase == 1 && d->OSY == 1 && d->OSX == 1 && d->GH == d->OH && d->GW == d->OW;
-    if (!flat || d->stats != nullptr || d->act != VG_ACT_NONE || d->mask_x != nullptr) return r;
+    if (!flat || d->stats != nullptr || d->act != VG_ACT_NONE || d->mask_x != nullptr || dtype == VG_FP8) return r;
     const int esz = dtype == VG_F32 ? 4 : 2;
     const int kch = dtype == VG_BF16 ? 2 : 1;
     const int nstages = ((d->Kp * esz) / 64 + kch - 1) / kch;
@@ -719,30 +771,38 @@ int launch(const vg_gg_desc* d, hipStream_t s, SplitK sk) {
     const int m_tiles = (M + BM - 1) / BM, n_tiles = (d->N + BN - 1) / BN;
     dim3 grid(((m_tiles + 7) / 8) * 8 * n_tiles, 1, split ? sk.ksplit : d->nphase);
     const int nstages_all = 1 << 30;
-    constexpr bool CAN_DMA = (DT == VG_BF16) && (BN % 64 == 0);
+    constexpr bool CAN_DMA = (DT == VG_BF16 || DT == VG_FP8) && (BN % 64 == 0);
     const bool dma = CAN_DMA && use_dma() && d->zeros != nullptr;
-    if (split) {
+    if constexpr (DT == VG_FP8) {
+        // LDS-DMA ring as the bf16 kernel (the staging code is byte-generic: a 64-byte chunk holds 64 e4m3 channels)
+        if (dma) vg_launch_timed(3, gg_kernel<DT, BM, BN, WM, WN, false, true>, grid, dim3(256), 0, s, *d, 1, nstages_all);
+        else vg_launch_timed(3, gg_kernel<DT, BM, BN, WM, WN, false, false>, grid, dim3(256), 0, s, *d, 1, nstages_all);
+        return VG_LAUNCH_RC();
+    } else if (split) {
         vg_launch_timed(0, gg_kernel<DT, BM, BN, WM, WN, true, false>, grid, dim3(256), 0, s, *d, sk.ksplit, sk.sps);
     } else if constexpr (CAN_DMA) {
         if (dma) vg_launch_timed(0, gg_kernel<DT, BM, BN, WM, WN, false, true>, grid, dim3(256), 0, s, *d, 1, nstages_all);
         else vg_launch_timed(0, gg_kernel<DT, BM, BN, WM, WN, false, false>, grid, dim3(256), 0, s, *d, 1, nstages_all);
     } else {
-        vg_launch_timed(0, gg_kernel<DT, BM, BN, WM, WN, false, false>, grid, dim3(256), 0, s, *d, 1, nstages_all);
+        vg_launch_timed(DT == VG_FP8 ? 3 : 0, gg_kernel<DT, BM, BN, WM, WN, false, false>, grid, dim3(256), 0, s, *d, 1, nstages_all);
     }
     int rc = VG_LAUNCH_RC();
     if (rc || !split) return rc;
     const int64_t total = (int64_t)M * d->OC;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(splitk_reduce_kernel<DT>, dim3(blocks), dim3(256), 0, s, d->ws, sk.ksplit, M, d->N, d->OC,
-                       m_tiles * BM, n_tiles * BN, d->bias, d->Y);
+    if constexpr (DT != VG_FP8)
+        hipLaunchKernelGGL(splitk_reduce_kernel<DT>, dim3(blocks), dim3(256), 0, s, d->ws, sk.ksplit, M, d->N, d->OC,
+                           m_tiles * BM, n_tiles * BN, d->bias, d->Y);
     return VG_LAUNCH_RC();
 }
 
 template <int DT>
 int dispatch(const vg_gg_desc* d, TileCfg t, hipStream_t s, SplitK sk) {
-    if (t.bm == 256 && t.bn == 16) return launch<DT, 256, 16, 4, 1>(d, s, sk);
-    if (t.bm == 128 && t.bn == 32) return launch<DT, 128, 32, 4, 1>(d, s, sk);
+    if constexpr (DT != VG_FP8) {
+        if (t.bm == 256 && t.bn == 16) return launch<DT, 256, 16, 4, 1>(d, s, sk);
+        if (t.bm == 128 && t.bn == 32) return launch<DT, 128, 32, 4, 1>(d, s, sk);
+    }
     if (t.bm == 128 && t.bn == 128) return launch<DT, 128, 128, 2, 2>(d, s, sk);
     if (t.bm == 128 && t.bn == 64) return launch<DT, 128, 64, 2, 2>(d, s, sk);
     return launch<DT, 64, 64, 2, 2>(d, s, sk);
@@ -753,7 +813,7 @@ int dispatch(const vg_gg_desc* d, TileCfg t, hipStream_t s, SplitK sk) {
 extern "C" int vg_gather_gemm_nparts(const vg_gg_desc* d, int dtype) {
     int rc = validate(d, dtype);
     if (rc) return rc;
-    TileCfg t = pick_tile(d, dtype == VG_BF16);
+    TileCfg t = pick_tile(d, dtype == VG_BF16, dtype == VG_FP8);
     const int M = d->B * d->GH * d->GW;
     return d->nphase * ((M + t.bm - 1) / t.bm);
 }
@@ -761,31 +821,32 @@ extern "C" int vg_gather_gemm_nparts(const vg_gg_desc* d, int dtype) {
 extern "C" int vg_gather_gemm_family(const vg_gg_desc* d, int dtype) {
     int rc = validate(d, dtype);
     if (rc) return rc;
-    return narrowk_ok(d, dtype) ? 2 : 0;
+    return dtype == VG_FP8 ? 3 : (narrowk_ok(d, dtype) ? 2 : 0);
 }
 
 extern "C" int vg_gather_gemm_tile_m(const vg_gg_desc* d, int dtype) {
     int rc = validate(d, dtype);
     if (rc) return rc;
-    return pick_tile(d, dtype == VG_BF16).bm;
+    return pick_tile(d, dtype == VG_BF16, dtype == VG_FP8).bm;
 }
 
 extern "C" int64_t vg_gather_gemm_ws_bytes(const vg_gg_desc* d, int dtype) {
     int rc = validate(d, dtype);
     if (rc) return rc;
-    return plan_splitk(d, dtype, pick_tile(d, dtype == VG_BF16)).ws_bytes;
+    return plan_splitk(d, dtype, pick_tile(d, dtype == VG_BF16, dtype == VG_FP8)).ws_bytes;
 }
 
 extern "C" int vg_gather_gemm(const vg_gg_desc* d, int dtype, void* stream) {
     int rc = validate(d, dtype);
     if (rc) return rc;
-    TileCfg t = pick_tile(d, dtype == VG_BF16);
+    TileCfg t = pick_tile(d, dtype == VG_BF16, dtype == VG_FP8);
     const SplitK sk = plan_splitk(d, dtype, t);
     if (d->stats) {
         const int M = d->B * d->GH * d->GW;
         VG_CHECK_ARG(d->stats_capacity >= d->nphase * ((M + t.bm - 1) / t.bm), VG_EINVAL);
     }
     if (dtype == VG_F32) return dispatch<VG_F32>(d, t, vg_stream(stream), sk);
+    if (dtype == VG_FP8) return dispatch<VG_FP8>(d, t, vg_stream(stream), sk);
     if (narrowk_ok(d, dtype)) return launch_narrowk(d, vg_stream(stream));
     PatchGeo pg;
     if ((t.bm == 128 || t.bm == 256) && (t.bn == GP_BN || (t.bn == 64 && patch64())) && sk.ksplit <= 1 &&

@@ -6,6 +6,30 @@
 
 namespace {
 
+// bf16 -> e4m3fn with a power-of-two pre-scale; 8 elements (16 B in, 8 B out) per thread and pass
+__global__ __launch_bounds__(256) void cast_fp8_kernel(const u32x4* __restrict__ x, uint2* __restrict__ y, int64_t nvec,
+                                                       float scale) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+        const u32x4 v = x[i];
+        float f[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            f[2 * k] = __uint_as_float(v[k] << 16) * scale;
+            f[2 * k + 1] = __uint_as_float(v[k] & 0xffff0000u) * scale;
+        }
+        uint2 o;
+        int w = 0;
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], w, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w, true);
+        o.x = (uint32_t)w;
+        w = 0;
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], w, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], w, true);
+        o.y = (uint32_t)w;
+        y[i] = o;
+    }
+}
+
 __global__ void rng_advance_kernel(unsigned long long* state) { state[1] += 1ull; }
 
 __global__ __launch_bounds__(256) void randn_fill_kernel(float* __restrict__ out, int64_t n, NoiseSrc src) {
@@ -485,6 +509,14 @@ extern "C" int vg_randn(float* out, int64_t n, const uint64_t* rng, int draw, vo
     return VG_LAUNCH_RC();
 }
 
+extern "C" int vg_cast_fp8(const void* x_bf16, void* y_fp8, int64_t n, int shift, void* stream) {
+    VG_CHECK_ARG(x_bf16 && y_fp8 && n > 0 && n % 8 == 0 && shift >= -16 && shift <= 16, VG_EINVAL);
+    VG_CHECK_ARG(vg_aligned16(x_bf16) && (reinterpret_cast<uintptr_t>(y_fp8) & 7u) == 0, VG_EALIGN);
+    hipLaunchKernelGGL(cast_fp8_kernel, dim3(blocks_for(n / 8)), dim3(256), 0, vg_stream(stream),
+                       reinterpret_cast<const u32x4*>(x_bf16), reinterpret_cast<uint2*>(y_fp8), n / 8, ldexpf(1.f, shift));
+    return VG_LAUNCH_RC();
+}
+
 extern "C" int vg_memset_zero(void* p, int64_t nbytes, void* stream) {
     VG_CHECK_ARG(p && nbytes > 0, VG_EINVAL);
     return (int)hipMemsetAsync(p, 0, (size_t)nbytes, vg_stream(stream));
@@ -701,7 +733,7 @@ extern "C" int vg_timing_enable(int on) {
 
 // Synchronises the recorded events of `family`, returns the summed kernel time and the launch count, recycles them.
 extern "C" int vg_timing_collect(int family, double* total_ms, int* launches) {
-    VG_CHECK_ARG(family >= 0 && family < 3 && total_ms && launches, VG_EINVAL);
+    VG_CHECK_ARG(family >= 0 && family < 4 && total_ms && launches, VG_EINVAL);
     VgTiming& t = vg_timing();
     std::lock_guard<std::mutex> g(t.mu);
     double sum = 0.0;

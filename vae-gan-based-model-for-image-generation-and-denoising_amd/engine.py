@@ -21,7 +21,7 @@ import torch
 
 from . import geometry as G
 from . import ops
-from ._lib import VG_ACT_LRELU, VG_ACT_NONE, VG_ACT_RELU, VG_ACT_TANH
+from ._lib import VG_ACT_LRELU, VG_ACT_NONE, VG_ACT_RELU, VG_ACT_TANH, VG_FP8_WSHIFT
 
 BN_MOMENTUM, BN_EPS = 0.1, 1e-5       # nn.BatchNorm2d defaults (main_vae.py:24, gan_code.py:22)
 
@@ -135,8 +135,10 @@ class GradSink:
 class StackEngine:
     """A chain of conv-like stages sharing one activation dtype."""
 
-    def __init__(self, stages: List[Stage], dtype: int, in_ch: int):
+    def __init__(self, stages: List[Stage], dtype: int, in_ch: int, fp8_fprop: bool = False):
         self.stages = stages
+        # forward GEMMs of the wide conv layers on e4m3 operands (bf16 engines only; BASELINE configs[4])
+        self.fp8_fprop = bool(fp8_fprop) and dtype == G.BF16
         self.dtype = dtype
         self.in_ch = in_ch
         self._specs: Dict = {}
@@ -170,6 +172,18 @@ class StackEngine:
                 sp = G.conv_fprop(*a)
             self._specs[key] = sp
         return sp
+
+    def fp8_ok(self, i: int) -> bool:
+        """Stage i's forward GEMM reads fp8 operands: a conv / convT whose packed bf16 operand has whole 64-element
+        K rows (then the fp8 operand is its elementwise cast) and >= 16 input channels; not the edge layers."""
+        key = (i, "fp8")
+        if key not in self._specs:
+            st, ok = self.stages[i], False
+            if self.fp8_fprop and st.kind in ("conv", "convT"):
+                gg, pk = self.spec(i, 1, "fprop")
+                ok = (not pk.tap_in_n and gg.IC % 16 == 0 and gg.Kp % 64 == 0 and self.tn(i, 1, "fprop") is None)
+            self._specs[key] = ok
+        return self._specs[key]
 
     def tn(self, i: int, B: int, what: str):
         """(TNSpec, PackSpec) when stage i's `what` ('fprop' of a narrow ConvTranspose2d, 'dgrad' of a narrow Conv2d)
@@ -221,6 +235,9 @@ class StackEngine:
             else:
                 ent["bias"] = st.conv.bias.detach() if st.has_bias else None
         ops.pack_weights_multi(self._pack_table, self._pack_n, self._pack_max, self.dtype)
+        for i in range(len(self.stages)):
+            if self.fp8_ok(i):                  # e4m3 twin of the forward operand, weights pre-scaled by 2^VG_FP8_WSHIFT
+                ops.cast_fp8(packs[i]["fprop"], VG_FP8_WSHIFT, out=packs[i]["fprop8"])
         self._pack_key = key
         return packs
 
@@ -248,6 +265,8 @@ class StackEngine:
                 _, pk = self.spec(i, 1, what)
                 ent[what] = torch.empty(pk.numel(), dtype=ops.TORCH_DT[self.dtype], device=dev)
                 descs.append(ops.pack_desc(pk, w, ent[what]))
+                if what == "fprop" and self.fp8_ok(i):
+                    ent["fprop8"] = torch.empty(pk.numel(), dtype=torch.uint8, device=dev)
                 if st.kind != "head" and self.tn(i, 1, what) is not None:      # edge-layer operand [(kh,kw,n)][C]
                     _, tpk = self.tn(i, 1, what)
                     ent["tn_" + what] = torch.empty(tpk.numel(), dtype=ops.TORCH_DT[self.dtype], device=dev)
@@ -280,8 +299,9 @@ class StackEngine:
                 if gg.nphase != 1 or pk.tap_in_n:
                     ok = False
                     break
-                xin = torch.empty(gg.B * gg.IH * gg.IW * gg.IC, dtype=ops.TORCH_DT[self.dtype], device=probe_x.device)
-                bm = ops.gather_gemm_tile_m(gg, xin, packs[i]["fprop"], self.dtype)
+                kdt, kop = (G.FP8, "fprop8") if self.fp8_ok(i) else (self.dtype, "fprop")
+                xin = torch.empty(gg.B * gg.IH * gg.IW * gg.IC, dtype=ops.TORCH_DT[kdt], device=probe_x.device)
+                bm = ops.gather_gemm_tile_m(gg, xin, packs[i][kop], kdt)
                 if (B * st.hout * st.hout) % bm != 0:
                     ok = False
                     break
@@ -297,6 +317,7 @@ class StackEngine:
         dt = self.dtype
         ctx = []
         a = x
+        a8 = None                             # e4m3 twin of `a` when the producing pass already made one (fp8 engines)
         Bg, B = B, B * groups
         for i, st in enumerate(self.stages):
             if st.kind == "head":
@@ -321,7 +342,7 @@ class StackEngine:
                     Yshape = tuple(out.shape)
                 if keep:
                     ctx.append({"x": a, "Y": None, "Yshape": Yshape, "coeffs": None, "rows": B * st.hout * st.hout, "OC": OC})
-                a = out
+                a, a8 = out, None
                 continue
             gg, pk = self.spec(i, B, "fprop")
             want_stats = st.bn is not None and train
@@ -331,9 +352,16 @@ class StackEngine:
             # a layer without BatchNorm gets its (Leaky)ReLU in the conv epilogue: "Y" is then the ACTIVATED output,
             # which carries the same sign information the activation's backward needs (slope >= 0)
             fuse_act = st.bn is None and st.act != VG_ACT_NONE
-            Y, stats, nparts = ops.gather_gemm(gg, a, packs[i]["fprop"], dt, bias=packs[i]["bias"],
-                                               want_stats=epilogue_stats, alg=st.alg(B, dt),
-                                               act=(st.act, st.slope) if fuse_act else None)
+            if self.fp8_ok(i):
+                # e4m3 copy of the input activation (elementwise, same NHWC layout), block-scaled fp8 MFMA, bf16 output
+                Y, stats, nparts = ops.gather_gemm(gg, a8 if a8 is not None else ops.cast_fp8(a), packs[i]["fprop8"], G.FP8,
+                                                   bias=packs[i]["bias"],
+                                                   want_stats=epilogue_stats, alg=st.alg(B, dt),
+                                                   act=(st.act, st.slope) if fuse_act else None)
+            else:
+                Y, stats, nparts = ops.gather_gemm(gg, a, packs[i]["fprop"], dt, bias=packs[i]["bias"],
+                                                   want_stats=epilogue_stats, alg=st.alg(B, dt),
+                                                   act=(st.act, st.slope) if fuse_act else None)
             OC = G.padc(st.cout, dt)
             Y = Y.view(B, st.hout, st.hout, OC)
             rows = B * st.hout * st.hout
@@ -349,12 +377,16 @@ class StackEngine:
                 else:
                     coeffs = ops.bn_eval_coeffs(bn.weight.detach(), bn.bias.detach(), bn.running_mean,
                                                 bn.running_var, BN_EPS)
-                out = ops.bn_act_forward(Y, coeffs, rows, OC, st.act, st.slope, dt)
+                nxt8 = i + 1 < len(self.stages) and self.stages[i + 1].kind != "head" and self.fp8_ok(i + 1)
+                if nxt8:                                    # the next layer's fp8 operand comes out of this same pass
+                    out, out8 = ops.bn_act_forward(Y, coeffs, rows, OC, st.act, st.slope, dt, want_fp8=True)
+                else:
+                    out, out8 = ops.bn_act_forward(Y, coeffs, rows, OC, st.act, st.slope, dt), None
             else:
-                out = Y                                     # activation (if any) already applied by the epilogue
+                out, out8 = Y, None                         # activation (if any) already applied by the epilogue
             if keep:
                 ctx.append({"x": a, "Y": Y, "coeffs": coeffs, "rows": rows, "OC": OC})
-            a = out
+            a, a8 = out, out8
         if train and any(st.bn is not None for st in self.stages):
             self.pending_bn_ticks += groups
         return a, (ctx, B, train)

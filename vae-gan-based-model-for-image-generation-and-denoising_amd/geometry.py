@@ -17,10 +17,11 @@ from dataclasses import dataclass
 from typing import List, Tuple
 
 F32, BF16 = 0, 1
+FP8 = 2          # e4m3 operands of the fp8 forward GEMMs (storage dtype of those engines stays BF16)
 
 
 def esize(dtype: int) -> int:
-    return 4 if dtype == F32 else 2
+    return {F32: 4, BF16: 2, FP8: 1}[dtype]
 
 
 def per16(dtype: int) -> int:

@@ -25,13 +25,23 @@ from .engine import GradSink, Stage, StackEngine
 
 _DT = {"fp32": G.F32, "float32": G.F32, "f32": G.F32, torch.float32: G.F32,
        "bf16": G.BF16, "bfloat16": G.BF16, torch.bfloat16: G.BF16}
+# "fp8": bf16 engine (storage, backward, optimizer masters as for "bf16") whose forward GEMMs of the wide conv layers read
+# e4m3 copies of their operands (BASELINE configs[4]: a roofline run, the reference has no fp8 semantics)
+_FP8_NAMES = ("fp8", "float8", "e4m3")
+
+
+
+def _is_fp8(dtype) -> bool:
+    return isinstance(dtype, str) and dtype in _FP8_NAMES
 
 
 def _dtype_code(dtype) -> int:
+    if _is_fp8(dtype):
+        return G.BF16
     try:
         return _DT[dtype]
     except KeyError:
-        raise ValueError(f"dtype must be 'fp32' or 'bf16', got {dtype!r}") from None
+        raise ValueError(f"dtype must be 'fp32', 'bf16' or 'fp8', got {dtype!r}") from None
 
 
 def _no_standalone(self, *a, **k):
@@ -231,7 +241,7 @@ class Encoder(_EngineNet):
             hin = hout
         stages.append(Stage("linear2", channels[-1], 2 * latent_dim, hin, 1, 0, hin, 1,
                             conv=self.fc_mu, conv2=self.fc_logvar))
-        self._engine = StackEngine(stages, self._dt, img_size[0])
+        self._engine = StackEngine(stages, self._dt, img_size[0], fp8_fprop=_is_fp8(dtype))
 
     # mulv-level API used by trainer.py (no mu/logvar split, no autograd)
     def engine_forward(self, x_nchw, keep=True):
@@ -302,7 +312,7 @@ class Generator(_EngineNet):
             h *= 2
         stages.append(Stage("convT", chans[-1], nc, 3, 1, 1, h, h, conv=self.main[3 * len(chans)]))
         assert h == img_size
-        self._engine = StackEngine(stages, self._dt, nz)
+        self._engine = StackEngine(stages, self._dt, nz, fp8_fprop=_is_fp8(dtype))
 
     def engine_forward(self, z_nhwc, B, keep=True, tail=None):
         """z_nhwc: [B,1,1,ZP] engine dtype -> (pre-tanh NHWC image, ctx).
@@ -364,7 +374,7 @@ class Discriminator(_EngineNet):
             h //= 2
         assert h == 4
         stages.append(Stage("head", chans[-1], 1, 4, 1, 0, 4, 1, conv=self.main[3 * len(chans) - 1]))
-        self._engine = StackEngine(stages, self._dt, nc)
+        self._engine = StackEngine(stages, self._dt, nc, fp8_fprop=_is_fp8(dtype))
 
     def engine_forward(self, x_nhwc, B, keep=True, groups=1):
         return self._engine.forward(x_nhwc, B, self.training, keep, groups=groups)

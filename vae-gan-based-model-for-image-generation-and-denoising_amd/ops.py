@@ -9,9 +9,9 @@ from ctypes import byref, c_int
 import torch
 
 from . import _lib as L
-from .geometry import BF16, F32, GGSpec, PackSpec, TNSpec, WGSpec, esize
+from .geometry import BF16, F32, FP8, GGSpec, PackSpec, TNSpec, WGSpec, esize
 
-TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16}
+TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16, FP8: torch.uint8}      # e4m3 bytes travel as uint8
 
 
 def _need_cuda(*ts):
@@ -60,7 +60,7 @@ class KernelTimer:
     """Live timing of the GEMM-class launches (bench.py's roofline leg): the library brackets each kernel with a
     HIP start/stop event pair on its launch stream (vg_timing_*); this object only adds up the algorithmic
     FLOP / bytes of the same launches.  Off by default."""
-    FAMILIES = {"gather_gemm": 0, "wgrad": 1, "edge": 2}
+    FAMILIES = {"gather_gemm": 0, "wgrad": 1, "edge": 2, "gather_gemm_fp8": 3}
 
     def __init__(self):
         self.acc = {k: dict(flops=0, bytes=0) for k in self.FAMILIES}
@@ -88,6 +88,53 @@ class KernelTimer:
 
 
 TIMER = None
+
+# ---- binding ---------------------------------------------------------------------------------------------------------
+# The kernels live behind the C ABI (include/vaegan_hip.h).  Two faces reach it from Python:
+#   "ctypes"   (default)  _lib.py marshals pointers and descriptor structs;
+#   "torchops"            the PyTorch-ROCm custom-op face: torch.ops.vaegan.* registered by libvaegan_torch_ops.so
+#                         (csrc_torch/vaegan_torch_ops.cpp, TORCH_LIBRARY + TORCH_LIBRARY_IMPL(CUDA)), a thin shim over
+#                         the SAME entry points.  Covers the GEMM-class and optimizer launches (gather_gemm, wgrad,
+#                         adam_step, bn_act_forward, pack_weights_multi); host-only queries stay on ctypes.
+# Select with VG_BINDING=torchops or ops.set_binding("torchops"); results are bit-identical (tests/test_gpu_binding.py).
+BINDING = "ctypes"
+_TORCH_OPS = None
+
+
+def torch_ops():
+    """torch.ops.vaegan, loading libvaegan_torch_ops.so on first use (RuntimeError if it was not built)."""
+    global _TORCH_OPS
+    if _TORCH_OPS is None:
+        import os
+        path = os.path.join(os.path.dirname(L.LIB_PATH), "libvaegan_torch_ops.so")
+        if not os.path.isfile(path):
+            raise RuntimeError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
+        L.load()                                   # libvaegan_hip.so first: the shim links against it
+        torch.ops.load_library(path)
+        if torch.ops.vaegan.abi_version() != L.ABI_VERSION:
+            raise RuntimeError("libvaegan_torch_ops.so was built against another libvaegan_hip ABI; rebuild")
+        _TORCH_OPS = torch.ops.vaegan
+    return _TORCH_OPS
+
+
+def set_binding(name: str) -> None:
+    global BINDING
+    if name not in ("ctypes", "torchops"):
+        raise ValueError("binding must be 'ctypes' or 'torchops'")
+    if name == "torchops":
+        torch_ops()
+    BINDING = name
+
+
+def _gg_geom(d) -> list:
+    return ([d.B, d.GH, d.GW, d.IH, d.IW, d.IC, d.SY, d.SX, d.DY, d.DX, d.TH, d.TW] + list(d.y0) + list(d.x0) +
+            [d.N, d.Kp, d.OH, d.OW, d.OC, d.OSY, d.OSX] + list(d.ooy) + list(d.oox) +
+            [d.nphase, d.stats_capacity, d.act, d.mask_act])
+
+
+def _wg_geom(d) -> list:
+    return [d.B, d.GH, d.GW, d.PC, d.NP, d.QH, d.QW, d.QC, d.NQ, d.SY, d.SX, d.DY, d.DX, d.TH, d.TW, d.y0, d.x0,
+            d.s_np, d.s_cq, d.s_t, d.accumulate]
 
 
 def set_timer(t) -> None:
@@ -209,6 +256,9 @@ def pack_table(descs, device):
 
 
 def pack_weights_multi(table: torch.Tensor, n: int, total_tiles: int, dtype: int) -> None:
+    if BINDING == "torchops":
+        torch_ops().pack_weights_multi(table, n, total_tiles, dtype)
+        return
     L.check(L.load().vg_pack_weights_multi(table.data_ptr(), n, total_tiles, dtype, L.stream_ptr()),
             "vg_pack_weights_multi")
 
@@ -244,7 +294,7 @@ def gather_gemm(g: GGSpec, X: torch.Tensor, Wp: torch.Tensor, dtype: int, bias: 
     if Wp.numel() != g.nphase * g.N * g.Kp:
         raise RuntimeError("gather_gemm: packed weight size mismatch")
     lib = L.load()
-    Y = out if out is not None else empty_act((g.B, g.OH, g.OW, g.OC), dtype, X.device)
+    Y = out if out is not None else empty_act((g.B, g.OH, g.OW, g.OC), BF16 if dtype == FP8 else dtype, X.device)
     if Y.numel() != g.B * g.OH * g.OW * g.OC:
         raise RuntimeError("gather_gemm: output size mismatch")
     stats, nparts = None, 0
@@ -263,17 +313,33 @@ def gather_gemm(g: GGSpec, X: torch.Tensor, Wp: torch.Tensor, dtype: int, bias: 
             raise RuntimeError("gather_gemm: mask tensor must be shaped and typed like the output")
         d.mask_x, d.mask_act, d.mask_slope = mx.data_ptr(), mact, mslope
     wsb = lib.vg_gather_gemm_ws_bytes(byref(d), dtype)
+    ws = None
     if wsb > 0:
         ws = WS.get("splitk", wsb, X.device)
         d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * 4
     tok = None
     if TIMER is not None:
-        fam = "edge" if lib.vg_gather_gemm_family(byref(d), dtype) == 2 else "gather_gemm"
+        fam = {0: "gather_gemm", 2: "edge", 3: "gather_gemm_fp8"}[lib.vg_gather_gemm_family(byref(d), dtype)]
         tok = TIMER.begin(fam, *(alg or (g.flops(), 0)))
-    L.check(lib.vg_gather_gemm(byref(d), dtype, L.stream_ptr()), "vg_gather_gemm")
+    if BINDING == "torchops":
+        torch_ops().gather_gemm(X, Wp, Y, bias, stats, ws if wsb > 0 else None, zero_page(X.device),
+                                mask[0] if mask is not None else None, _gg_geom(d), float(d.act_slope),
+                                float(d.mask_slope), dtype)
+    else:
+        L.check(lib.vg_gather_gemm(byref(d), dtype, L.stream_ptr()), "vg_gather_gemm")
     if tok is not None:
         TIMER.end(tok)
     return Y, stats, nparts
+
+
+def cast_fp8(x: torch.Tensor, shift: int = 0, out: torch.Tensor = None) -> torch.Tensor:
+    """bf16 -> e4m3 bytes (uint8 tensor of the same shape), y = fp8(x * 2^shift)."""
+    _need_cuda(x, out)
+    if x.dtype != torch.bfloat16 or x.numel() % 8:
+        raise RuntimeError("cast_fp8: bf16 input with a multiple of 8 elements")
+    y = out if out is not None else torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    L.check(L.load().vg_cast_fp8(x.data_ptr(), y.data_ptr(), x.numel(), shift, L.stream_ptr()), "vg_cast_fp8")
+    return y
 
 
 def tnconv(tn: TNSpec, X: torch.Tensor, Wp: torch.Tensor, want_nhwc: bool = True, want_nchw: bool = False,
@@ -327,7 +393,10 @@ def wgrad(wg: WGSpec, P: torch.Tensor, Q: torch.Tensor, dW: torch.Tensor, accumu
     d.ws = ws.data_ptr()
     d.ws_bytes = ws.numel() * 4
     tok = TIMER.begin("wgrad", *(alg or (0, 0))) if TIMER is not None else None
-    L.check(lib.vg_wgrad(byref(d), dtype, L.stream_ptr()), "vg_wgrad")
+    if BINDING == "torchops":
+        torch_ops().wgrad(P, Q, dW, ws, zero_page(P.device), _wg_geom(d), dtype)
+    else:
+        L.check(lib.vg_wgrad(byref(d), dtype, L.stream_ptr()), "vg_wgrad")
     if tok is not None:
         TIMER.end(tok)
 
@@ -378,11 +447,22 @@ def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps):
     return co
 
 
-def bn_act_forward(x, coeffs, rows, C, act, slope, dtype, out=None):
-    """coeffs: [groups][4][C] (or None for a pure activation)."""
+def bn_act_forward(x, coeffs, rows, C, act, slope, dtype, out=None, want_fp8=False):
+    """coeffs: [groups][4][C] (or None for a pure activation).  want_fp8: -> (y, e4m3 copy of y as uint8)."""
     _need_cuda(x, coeffs)
     y = out if out is not None else torch.empty_like(x)
     groups = coeffs.shape[0] if coeffs is not None else 1
+    if want_fp8:
+        y8 = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+        L.check(L.load().vg_bn_act_forward_fp8(x.data_ptr(), y.data_ptr(), y8.data_ptr(),
+                                               coeffs[0, 2].data_ptr() if coeffs is not None else 0,
+                                               coeffs[0, 3].data_ptr() if coeffs is not None else 0, rows, C, act, slope,
+                                               groups, 4 * C, dtype, L.stream_ptr()), "vg_bn_act_forward_fp8")
+        return y, y8
+    if BINDING == "torchops":
+        torch_ops().bn_act_forward(x, y, coeffs[0, 2] if coeffs is not None else None,
+                                   coeffs[0, 3] if coeffs is not None else None, rows, C, act, float(slope), groups, 4 * C, dtype)
+        return y
     sc = coeffs[0, 2].data_ptr() if coeffs is not None else 0
     sh = coeffs[0, 3].data_ptr() if coeffs is not None else 0
     L.check(L.load().vg_bn_act_forward(x.data_ptr(), y.data_ptr(), sc, sh, rows, C, act, slope, groups, 4 * C, dtype,
@@ -654,5 +734,13 @@ def axpy(a, b, alpha, out=None):
 
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, grad_scale, state):
     _need_cuda(p, g, m, v, state)
+    if BINDING == "torchops":
+        torch_ops().adam_step(p, g, m, v, lr, beta1, beta2, eps, grad_scale, state)
+        return
     L.check(L.load().vg_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1,
                                   beta2, eps, grad_scale, state.data_ptr(), L.stream_ptr()), "vg_adam_step")
+
+
+import os as _os
+if _os.environ.get("VG_BINDING"):
+    set_binding(_os.environ["VG_BINDING"])
