@@ -158,13 +158,27 @@ def test_per_replica_bn_ranks_stay_consistent_eager_and_graphed(tmp_path):
 
 
 
-@pytest.mark.parametrize("sync_bn,graph", [(1, 0), (0, 1)])
+def test_syncbn_graph_replay_equals_eager_under_a_process_group(tmp_path):
+    """SyncBN mode under hipGraph replay: the statistics all-reduce of every BatchNorm (forward and backward) is a
+    graph cut -- the collectives run between segment replays on static f64 buffers -- and the replayed iterations
+    equal the eager ones bit for bit, with the same number of statistics collectives."""
+    S, GB, steps = 64, 8, 3
+    eager = _launch(tmp_path, 2, S, GB, steps, 1, 0)
+    graph = _launch(tmp_path, 2, S, GB, steps, 1, 1)
+    for k in eager[0]:
+        if k.startswith(("par_", "buf_")) or k == "losses":
+            assert np.array_equal(eager[0][k], graph[0][k]), k
+            assert np.array_equal(graph[0][k], graph[1][k]) or k == "losses", k
+    assert int(eager[0]["stat_collectives"]) == int(graph[0]["stat_collectives"]) > 0
+
+
+@pytest.mark.parametrize("sync_bn,graph", [(1, 0), (0, 1), (1, 1)])
 def test_single_rank_over_rccl_equals_single_process(tmp_path, sync_bn, graph):
     """The collectives themselves over RCCL (backend "nccl"), which the shared-GPU gloo tests above cannot reach: one
     rank per GPU means one rank here.  SyncBN mode (f64 statistics all-reduces inside every BatchNorm, eager) and
     throughput mode (flat-buffer gradient all-reduces between hipGraph segments, 3 iterations: eager, capture,
     replay).  With one rank every reduction is the identity, so the run must reproduce the single-process one."""
-    S, GB, steps = 64, 8, (1 if sync_bn else 3)
+    S, GB, steps = 64, 8, (1 if (sync_bn and not graph) else 3)
     r0 = _launch(tmp_path, 1, S, GB, steps, sync_bn, graph, backend="nccl")[0]
     one = _single_process(S, GB, steps, 2e-4)
     tol = [1e-5, 1e-5, 5e-4, 1e-5, 5e-4]           # first iteration (FIRST_STEP_TOL)

@@ -29,14 +29,14 @@ void rc_check(int rc, const char* what) {
                 rc == VG_ENOSUP ? "VG_ENOSUP unsupported configuration" : "HIP launch error", ", code ", rc, ")");
 }
 
-// geom: the int32 fields of vg_gg_desc from B to nphase in declaration order (43 values: y0/x0/ooy/oox are 4 each),
-// then stats_capacity, act, mask_act
+// geom: the int32 fields of vg_gg_desc from B to nphase in declaration order (y0/x0/ooy/oox are 4 each),
+// then stats_capacity, act, mask_act (39 values in all)
 int64_t gather_gemm(const at::Tensor& X, const at::Tensor& W, at::Tensor& Y, const c10::optional<at::Tensor>& bias,
                     const c10::optional<at::Tensor>& stats, const c10::optional<at::Tensor>& ws, const at::Tensor& zeros,
                     const c10::optional<at::Tensor>& mask_x, at::IntArrayRef geom, double act_slope, double mask_slope,
                     int64_t dtype) {
     check_dev(X, "gather_gemm"); check_dev(W, "gather_gemm"); check_dev(Y, "gather_gemm"); check_dev(zeros, "gather_gemm");
-    TORCH_CHECK(geom.size() == 46, "vaegan::gather_gemm: geom must hold 46 integers, got ", geom.size());
+    TORCH_CHECK(geom.size() == 39, "vaegan::gather_gemm: geom must hold 39 integers, got ", geom.size());
     vg_gg_desc d;
     std::memset(&d, 0, sizeof(d));
     d.X = X.data_ptr(); d.W = W.data_ptr(); d.Y = Y.data_ptr();

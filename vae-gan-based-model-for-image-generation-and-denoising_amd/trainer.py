@@ -18,6 +18,22 @@ from .engine import GradSink
 LOSS_NAMES = ("recon_loss", "kl_loss", "g_loss_adv", "d_loss_1", "d_loss_2")
 
 
+class _SyncBNHandoff:
+    """What the engines see as `bn_sync` in SyncBN mode: the statistics all-reduce of every BatchNorm goes through the
+    trainer's graph cut, so that under hipGraph capture the collective stays OUTSIDE the captured segments (it is
+    re-issued between segment replays on the same static f64 buffer) and runs immediately in eager mode."""
+
+    def __init__(self, trainer):
+        self.trainer = trainer
+
+    @property
+    def world(self):
+        return self.trainer.reducer.world
+
+    def all_reduce_sum(self, t):
+        self.trainer._cut(lambda: self.trainer.reducer.all_reduce_sum(t))
+
+
 class VAEGANTrainer:
     def __init__(self, encoder, decoder, discriminator, opt_E, opt_Dec, opt_Dis, alpha_kl: float = 0.1,
                  alpha_adv: float = 0.1, noise_sigma: float = 0.05, real_label: float = 0.9, fake_label: float = 0.1,
@@ -38,7 +54,7 @@ class VAEGANTrainer:
         if self.sync_bn and reducer is None:
             raise ValueError("sync_bn=True needs a ddp.GradReducer (reducer=...)")
         for net in (encoder, decoder, discriminator):
-            net._engine.bn_sync = reducer if self.sync_bn else None
+            net._engine.bn_sync = _SyncBNHandoff(self) if self.sync_bn else None
         dts = {encoder._dt, decoder._dt, discriminator._dt}
         if len(dts) != 1:
             raise ValueError("encoder / decoder / discriminator must share one engine dtype")
@@ -236,13 +252,11 @@ class VAEGANTrainer:
         replays, later calls replay.  Inputs are copied into static buffers; noise is either injected on every
         call or drawn on the device inside the graph (torch's graph-safe Philox state).
         With a gradient reducer the iteration is captured as SEGMENTS that share one memory pool, cut at the points
-        where gradients are handed to the reducer; the collectives run eagerly between the segment replays (the
-        generator's all-reduce is asynchronous and overlaps the segment holding the encoder's backward)."""
+        where gradients are handed to the reducer (one cut per gradient bucket, ddp.py) and, in SyncBN mode, at every
+        BatchNorm's statistics all-reduce; the collectives run eagerly between the segment replays."""
         inject = eps_z is not None
         if inject and (eps_real is None or eps_recon is None):
             raise ValueError("inject all three noise tensors or none")
-        if self.sync_bn:        # a collective inside every BatchNorm: run the iteration eagerly (parity mode)
-            return self.train_step(real, epoch, eps_z, eps_real, eps_recon)
         if not inject:
             self._noise_stream(real.device)         # exists (and is keyed on the current seed) before the key is formed
         key = self._capture_key(real, epoch, inject)
