@@ -267,6 +267,25 @@ typedef struct vg_tn_desc {
     float sigma;
     int32_t B, IH, IW, C, N, K, S, P, OH, OW, OC, Wpitch, act;
 } vg_tn_desc;
+/* Weight gradient of the edge layers, bf16 operands, f32 result:
+ *     dW[c*s_c + n*s_n + kh*K + kw] (+)= sum_{b,py,px} Wd[b][py][px][c] * Nr[b][py*S - P + kh][px*S - P + kw][n]
+ * Wd: the WIDE operand [B][WH][WW][C] (C = 32 | 64): dY of nn.Conv2d(N, C, K, S, P) (gan_code.py:61, main_vae.py:23 --
+ * then dW is the [C][N][K][K] weight gradient, s_c = N*K*K, s_n = K*K) or the input of nn.ConvTranspose2d(C, N, K, S, P)
+ * (gan_code.py:49 -- dW is [C][N][K][K] as well).  Nr: the 3-channel tensor on the other side, [B][NH][NW][8] bf16 with
+ * channels >= N zero (the image, or the image gradient).  N <= 3, K = 3 | 4, S = 1 | 2.
+ * ws: vg_edge_wgrad_ws_bytes() bytes of scratch (one [K*K*4 padded][C] f32 partial per workgroup, summed in fixed
+ * order: bitwise reproducible).  zeros: >= 64 readable zero bytes. */
+typedef struct vg_ew_desc {
+    const void* Wd;
+    const void* Nr;
+    float* dW;
+    float* ws;
+    int64_t ws_bytes;
+    const void* zeros;
+    int32_t B, WH, WW, C, NH, NW, N, K, S, P, s_c, s_n, accumulate;
+} vg_ew_desc;
+int64_t vg_edge_wgrad_ws_bytes(const vg_ew_desc* d);
+int vg_edge_wgrad(const vg_ew_desc* d, void* stream);
 int vg_tnconv_supported(const vg_tn_desc* d);     /* 0 if vg_tnconv takes this shape, else the error code */
 int vg_tnconv(const vg_tn_desc* d, void* stream);
 

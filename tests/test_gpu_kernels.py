@@ -270,6 +270,46 @@ def test_edge_layer_kernel_rejects_what_it_does_not_take(ops):
         ops.tnconv(tn, x, torch.zeros(5, dtype=torch.bfloat16, device=DEV))
 
 
+@pytest.mark.parametrize("kind,C,k,s,p,H,B", [("conv", 64, 4, 2, 1, 64, 3),     # Discriminator's first layer, S=64 (gan_code.py:61)
+                                              ("convT", 64, 3, 1, 1, 64, 2),   # Generator's last layer, S=64 (gan_code.py:49)
+                                              ("conv", 32, 4, 2, 0, 64, 2),    # Encoder's first layer: 31x31 outputs, p=0
+                                              ("conv", 32, 4, 2, 1, 128, 1),   # S=128 members
+                                              ("convT", 32, 3, 1, 1, 128, 1),
+                                              ("conv", 64, 4, 2, 1, 16, 5)])   # many images per workgroup walk, tiny maps
+def test_edge_layer_weight_gradient_vs_torch(ops, kind, C, k, s, p, H, B):
+    """vg_edge_wgrad (transposed LDS reads of both operands, narrow operand read straight from the image patch) against
+    torch's convolution weight gradient in fp64 on the bf16-rounded operands; plain and accumulating."""
+    g = torch.Generator().manual_seed(C + k + H)
+    if kind == "conv":
+        x = torch.randn(B, 3, H, H, generator=g)
+        OH = G.conv_out(H, k, s, p)
+        dy = torch.randn(B, C, OH, OH, generator=g)
+        xq = _q(x, G.BF16).requires_grad_(False)
+        w = torch.zeros(C, 3, k, k, dtype=torch.float64, requires_grad=True)
+        (F.conv2d(xq, w, stride=s, padding=p) * _q(dy, G.BF16)).sum().backward()
+        ew = G.conv_wgrad_edge(B, H, H, 3, C, k, s, p, G.BF16)
+        wide, narrow = _dev(to_nhwc(dy, C), G.BF16, ops), _dev(to_nhwc(x, 8), G.BF16, ops)
+    else:
+        x = torch.randn(B, C, H, H, generator=g)
+        OH = G.convT_out(H, k, s, p)
+        dy = torch.randn(B, 3, OH, OH, generator=g)
+        w = torch.zeros(C, 3, k, k, dtype=torch.float64, requires_grad=True)
+        (F.conv_transpose2d(_q(x, G.BF16), w, stride=s, padding=p) * _q(dy, G.BF16)).sum().backward()
+        ew = G.convT_wgrad_edge(B, H, H, C, 3, k, s, p, G.BF16)
+        wide, narrow = _dev(to_nhwc(x, C), G.BF16, ops), _dev(to_nhwc(dy, 8), G.BF16, ops)
+    assert ew is not None
+    ref = w.grad
+    dW = torch.full((C, 3, k, k), float("nan"), device=DEV)
+    ops.edge_wgrad(ew, wide, narrow, dW, False)
+    close(dW.double().cpu(), ref, G.F32, f32=(1e-4, 2e-5))            # exact bf16 products, f32 accumulation
+    ops.edge_wgrad(ew, wide, narrow, dW, True)                        # accumulate: twice the gradient
+    close(dW.double().cpu(), 2 * ref, G.F32, f32=(1e-4, 4e-5))
+    first = dW.clone()
+    ops.edge_wgrad(ew, wide, narrow, dW, False)
+    ops.edge_wgrad(ew, wide, narrow, first, False)
+    assert torch.equal(first, dW)                                     # fixed summation order: bitwise reproducible
+
+
 def _e4m3(t):
     """Round to OCP e4m3fn the way the kernels' operands are (torch's float8_e4m3fn cast: round to nearest even)."""
     return t.float().to(torch.float8_e4m3fn).double()

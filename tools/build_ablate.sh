@@ -10,5 +10,5 @@ for f in conv_gemm wgrad; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I"$ROOT/include" -I"$C" -Wno-unused-function $FLAGS -c "$C/$f.hip" -o "$ROOT/scratch/abl_$NAME/$f.o" &
 done
 wait
-hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/scratch/libvg_$NAME.so" "$ROOT/scratch/abl_$NAME/conv_gemm.o" "$ROOT/scratch/abl_$NAME/wgrad.o" "$C/bn_act.o" "$C/pointwise.o" "$C/pack_adam.o"
+hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/scratch/libvg_$NAME.so" "$ROOT/scratch/abl_$NAME/conv_gemm.o" "$ROOT/scratch/abl_$NAME/wgrad.o" "$C/bn_act.o" "$C/pointwise.o" "$C/pack_adam.o" "$C/edge_conv.o"
 echo built scratch/libvg_$NAME.so

@@ -58,6 +58,15 @@ class TNDesc(Structure):
                 ("Wpitch", c_int32), ("act", c_int32)]
 
 
+class EWDesc(Structure):
+    """vg_ew_desc."""
+    _fields_ = [("Wd", c_void_p), ("Nr", c_void_p), ("dW", c_void_p), ("ws", c_void_p), ("ws_bytes", c_int64),
+                ("zeros", c_void_p),
+                ("B", c_int32), ("WH", c_int32), ("WW", c_int32), ("C", c_int32), ("NH", c_int32), ("NW", c_int32),
+                ("N", c_int32), ("K", c_int32), ("S", c_int32), ("P", c_int32), ("s_c", c_int32), ("s_n", c_int32),
+                ("accumulate", c_int32)]
+
+
 class PackDesc(Structure):
     """vg_pack_desc."""
     _fields_ = [("src", c_void_p), ("dst", c_void_p),
@@ -129,6 +138,8 @@ SIGNATURES = {
     "vg_reparam_kl_backward_rng": (c_int, [_P, _P, _P, _I, _P, _F, _P, _I, _I, _I, _I, _I, _P]),
     "vg_memset_zero": (c_int, [_P, _L, _P]),
     "vg_cast_fp8": (c_int, [_P, _P, _L, _I, _P]),
+    "vg_edge_wgrad_ws_bytes": (c_int64, [POINTER(EWDesc)]),
+    "vg_edge_wgrad": (c_int, [POINTER(EWDesc), _P]),
     "vg_tnconv_supported": (c_int, [POINTER(TNDesc)]),
     "vg_tnconv": (c_int, [POINTER(TNDesc), _P]),
 }

@@ -191,6 +191,196 @@ inline void tn_launch(const vg_tn_desc* d, const TnPlan& p, hipStream_t s) {
     else vg_launch_timed(2, (tnconv_kernel<NT, KC, NPIX, 4, 2>), grid, block, 0, s, *d, p.RO, p.tiles_y);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// vg_edge_wgrad -- weight gradient of the edge layers (the Discriminator's / Encoder's first Conv2d, the Generator's
+// last ConvTranspose2d):   G[j = (kh*K + kw)*4 + n][c] = sum_pix  Nr[b][py*S - P + kh][px*S - P + kw][n] * Wd[b][py][px][c]
+// over the pixels (b, py, px) of the WIDE operand Wd (C = 32 | 64 channels: dY of the conv, the input of the convT);
+// Nr is the 3-channel tensor on the other side (the image, or the image gradient), 8 bf16 per pixel, channel 3 is zero.
+// The generic wgrad kernel (wgrad.hip) runs this as a 128 x 128 tile of which 1/4 is used, gathers the narrow operand
+// in 16-byte granules through LDS-DMA and writes 17-33 MB of split slabs for a 3 K-element result.  Here:
+//   * a workgroup loops over tiles of 256 wide pixels (whole grid rows); the wide tile goes HBM -> LDS by LDS-DMA
+//     (each byte read once), the narrow receptive field of the tile (a (R*S + K - S) x ((W-1)*S + K) pixel patch)
+//     is staged once, zero-filled outside the image;
+//   * both MFMA operands have the pixel as reduction index, i.e. the strided dimension of both tensors: fragments
+//     come from ds_read_b64_tr_b16 (cdna_hip_programming.md T10).  The narrow fragment is read STRAIGHT from the
+//     patch: lane (k row q, column quad p) of a 16-lane group supplies the address of the 4 channels of tap p of pixel
+//     q -- the im2col matrix is never materialised.  The wide tile's 32-byte column blocks are XOR-swizzled with
+//     (pixel >> 1) & 3 (C = 64; (pixel >> 2) & 1 for C = 32) on the DMA source side: conflict-free transposed reads;
+//   * wave w owns the 16 rows j = 16w .. 16w+15 (4 taps) x all C columns; accumulators live across the workgroup's
+//     tiles; one [J][C] f32 partial per workgroup, summed in fixed order by edge_wgrad_reduce_kernel, which also
+//     scatters into the reference layout dW[c*s_c + n*s_n + kh*K + kw].
+constexpr int EW_TP = 256;                 // wide pixels per tile
+
+typedef __attribute__((ext_vector_type(4))) __bf16 ew_bf16x4;
+
+template <int CT>                          // C = 16 * CT channels of the wide operand (CT = 2 | 4)
+__global__ __launch_bounds__(256) void edge_wgrad_kernel(const vg_ew_desc d, const int R, const int tiles_per_img,
+                                                         const int ntiles, const int JT) {
+    constexpr int RB = CT * 32;                                   // bytes per wide pixel
+    constexpr int PATCH_MAX = 22 * 1024;
+    // [wide tile 256 x RB][patch: slot 0 = zero pixel, then PR x PW pixels of 16 B][pixel table 256 x int]
+    __shared__ __attribute__((aligned(16))) unsigned char smem[EW_TP * RB + PATCH_MAX + EW_TP * 4];
+    unsigned char* const wide = smem;
+    unsigned char* const patch = smem + EW_TP * RB;
+    int* const ptab = reinterpret_cast<int*>(smem + EW_TP * RB + PATCH_MAX);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const int PW = (d.WW - 1) * d.S + d.K, PR = (R - 1) * d.S + d.K;
+    // this lane's tap (column quad p of j tile `wave`): byte offset inside the patch, or the zero pixel
+    const int tap = wave * 4 + p;
+    const int kh = tap / d.K, kw = tap - kh * d.K;
+    const bool tap_ok = tap < d.K * d.K;
+    const int tapoff = tap_ok ? (kh * PW + kw) * 16 : 0;
+
+    f32x4 acc[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const unsigned char* Wb = reinterpret_cast<const unsigned char*>(d.Wd);
+    const unsigned char* Nb = reinterpret_cast<const unsigned char*>(d.Nr);
+    const unsigned char* Zp = reinterpret_cast<const unsigned char*>(d.zeros);
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / tiles_per_img, ty = tile - b * tiles_per_img;
+        const int py0 = ty * R;
+        const int rows = min(R, d.WH - py0);                       // last tile of an image may be short
+        const int npix = rows * d.WW;
+        __syncthreads();                                           // previous tile's fragment reads are done
+        // ---- wide tile: LDS-DMA, 1 KiB per wave instruction, source block swizzled by the pixel ----
+        {
+            constexpr int PPI = 1024 / RB;                         // pixels per wave instruction (8 | 16)
+            constexpr int UPP = RB / 16;                           // 16-byte units per pixel (8 | 4)
+            const unsigned char* base = Wb + ((int64_t)(b * d.WH + py0) * d.WW) * RB;
+#pragma unroll
+            for (int it = 0; it < EW_TP / PPI / 4; ++it) {
+                const int i0 = (it * 4 + wave_u) * PPI;            // first pixel of this wave instruction
+                const int pix = i0 + lane / UPP, u = lane % UPP;
+                const int f = CT == 4 ? ((pix >> 1) & 3) : ((pix >> 2) & 1);
+                const int su = (((u >> 1) ^ f) << 1) | (u & 1);    // source unit that belongs at LDS unit u
+                const unsigned char* src = pix < npix ? base + (int64_t)pix * RB + su * 16 : Zp;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(wide + i0 * RB), 16, 0, 0);
+            }
+        }
+        // ---- narrow patch (zero outside the image) and the pixel table ----
+        const int ny0 = py0 * d.S - d.P;
+        for (int e = tid; e < PR * PW; e += 256) {
+            const int pr = e / PW, pc = e - pr * PW;
+            const int ny = ny0 + pr, nx = pc - d.P;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if ((unsigned)ny < (unsigned)d.NH && (unsigned)nx < (unsigned)d.NW)
+                v = *reinterpret_cast<const u32x4*>(Nb + ((int64_t)(b * d.NH + ny) * d.NW + nx) * 16);
+            *reinterpret_cast<u32x4*>(patch + 16 + e * 16) = v;
+        }
+        if (tid == 0) *reinterpret_cast<u32x4*>(patch) = u32x4{0u, 0u, 0u, 0u};
+        {
+            const int pyl = tid / d.WW, px = tid - pyl * d.WW;
+            ptab[tid] = tid < npix ? 16 + (pyl * d.S * PW + px * d.S) * 16 : 0;     // pad pixels: wide rows are zero anyway
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // ---- MFMA over the tile's pixels: 32 per step ----
+        if (wave_u < JT) {
+            const int nsteps = (npix + 31) >> 5;
+            for (int ks = 0; ks < nsteps; ++ks) {
+                const int r0 = ks * 32 + 4 * g + q, r1 = r0 + 16;
+                // narrow fragment: 4 channels of tap p of pixels r0 / r1 (the zero pixel for padded taps)
+                const unsigned char* a0 = patch + (tap_ok ? ptab[r0] + tapoff : 0);
+                const unsigned char* a1 = patch + (tap_ok ? ptab[r1] + tapoff : 0);
+                const ew_bf16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) ew_bf16x4*)a0);
+                const ew_bf16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) ew_bf16x4*)a1);
+                const bf16x8 af = __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7);
+                const int f0 = CT == 4 ? ((r0 >> 1) & 3) : ((r0 >> 2) & 1);
+                const int f1 = CT == 4 ? ((r1 >> 1) & 3) : ((r1 >> 2) & 1);
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    const unsigned char* b0 = wide + r0 * RB + ((c ^ f0) << 5) + 8 * p;
+                    const unsigned char* b1 = wide + r1 * RB + ((c ^ f1) << 5) + 8 * p;
+                    const ew_bf16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) ew_bf16x4*)b0);
+                    const ew_bf16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) ew_bf16x4*)b1);
+                    const bf16x8 bf = __builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, acc[c], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- partial [J][C] of this workgroup: rows j = 16*wave + 4*(lane>>4) + r, column c = 16*ct + (lane & 15) ----
+    if (wave_u < JT) {
+        float* out = d.ws + (int64_t)blockIdx.x * (JT * 16) * (CT * 16);
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                out[(wave * 16 + (lane >> 4) * 4 + r) * (CT * 16) + c * 16 + (lane & 15)] = acc[c][r];
+    }
+}
+
+// Two-level fixed-order sum of the workgroups' partials (a one-level loop over ~500 partials is a chain of dependent
+// HBM round trips: it cost more than the kernel it finishes).  Level 1: block (chunk of 256 outputs, group of parts)
+// sums its <= nparts/EW_G partials, 8 loads in flight per thread, whole 1-KiB rows per wave.  Level 2: EW_G partials per
+// output, scatter into dW[c*s_c + n*s_n + tap].
+constexpr int EW_G = 16;
+
+__global__ __launch_bounds__(256) void edge_wgrad_reduce1_kernel(const float* __restrict__ ws, float* __restrict__ ws2,
+                                                                 int nparts, int JC) {
+    const int idx = blockIdx.x * 256 + threadIdx.x, grp = blockIdx.y;
+    const int per = (nparts + EW_G - 1) / EW_G;
+    const int k0 = grp * per, k1 = min(nparts, k0 + per);
+    float s = 0.f;
+    int k = k0;
+    for (; k + 8 <= k1; k += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = ws[(int64_t)(k + u) * JC + idx];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < k1; ++k) s += ws[(int64_t)k * JC + idx];
+    ws2[(int64_t)grp * JC + idx] = s;
+}
+
+__global__ __launch_bounds__(256) void edge_wgrad_reduce2_kernel(const vg_ew_desc d, const float* __restrict__ ws2, int J, int C) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;               // = j * C + c
+    if (idx >= J * C) return;
+    const int j = idx / C, c = idx - j * C;
+    const int n = j & 3, tap = j >> 2;
+    if (n >= d.N || tap >= d.K * d.K) return;
+    float v[EW_G];
+#pragma unroll
+    for (int g = 0; g < EW_G; ++g) v[g] = ws2[(int64_t)g * J * C + idx];
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < EW_G; ++g) s += v[g];
+    float* dst = d.dW + (int64_t)c * d.s_c + (int64_t)n * d.s_n + tap;
+    *dst = d.accumulate ? *dst + s : s;
+}
+
+struct EwPlan { int R, tiles_per_img, ntiles, JT, CT, grid; int64_t ws_bytes; };
+
+inline int ew_plan(const vg_ew_desc* d, EwPlan* p) {
+    VG_CHECK_ARG(d != nullptr, VG_EINVAL);
+    VG_CHECK_ARG(d->B > 0 && d->WH > 0 && d->WW > 0 && d->NH > 0 && d->NW > 0 && d->P >= 0, VG_EINVAL);
+    VG_CHECK_ARG(d->C == 32 || d->C == 64, VG_ENOSUP);
+    VG_CHECK_ARG(d->N >= 1 && d->N <= 3, VG_ENOSUP);              // channel 3 of the narrow operand must be the zero pad
+    VG_CHECK_ARG((d->K == 3 || d->K == 4) && (d->S == 1 || d->S == 2), VG_ENOSUP);
+    VG_CHECK_ARG(d->WW <= EW_TP, VG_ENOSUP);
+    p->JT = (d->K * d->K * 4 + 15) / 16;                           // 3 (k3) | 4 (k4)
+    p->CT = d->C / 16;
+    int R = EW_TP / d->WW;
+    while (R > 1 && (int64_t)(((R - 1) * d->S + d->K) * ((d->WW - 1) * d->S + d->K) + 1) * 16 > 22 * 1024) --R;
+    VG_CHECK_ARG((int64_t)(((R - 1) * d->S + d->K) * ((d->WW - 1) * d->S + d->K) + 1) * 16 <= 22 * 1024, VG_ENOSUP);
+    if (R > d->WH) R = d->WH;
+    p->R = R;
+    p->tiles_per_img = (d->WH + R - 1) / R;
+    p->ntiles = d->B * p->tiles_per_img;
+    p->grid = p->ntiles < 512 ? p->ntiles : 512;                   // 2 workgroups per CU, each walks several tiles
+    p->ws_bytes = (int64_t)(p->grid + EW_G) * p->JT * 16 * d->C * 4;   // partials + the level-1 sums
+    return 0;
+}
+
 }  // namespace
 
 extern "C" int vg_tnconv_supported(const vg_tn_desc* d) {
@@ -210,5 +400,30 @@ extern "C" int vg_tnconv(const vg_tn_desc* d, void* stream) {
         if (p.NT == 1) tn_launch<1, 2>(d, p, s); else if (p.NT == 2) tn_launch<2, 2>(d, p, s);
         else if (p.NT == 3) tn_launch<3, 2>(d, p, s); else tn_launch<4, 2>(d, p, s);
     }
+    return VG_LAUNCH_RC();
+}
+
+extern "C" int64_t vg_edge_wgrad_ws_bytes(const vg_ew_desc* d) {
+    EwPlan p;
+    int rc = ew_plan(d, &p);
+    return rc ? (int64_t)rc : p.ws_bytes;
+}
+
+extern "C" int vg_edge_wgrad(const vg_ew_desc* d, void* stream) {
+    EwPlan p;
+    int rc = ew_plan(d, &p);
+    if (rc) return rc;
+    VG_CHECK_ARG(d->Wd && d->Nr && d->dW && d->ws && d->zeros, VG_EINVAL);
+    VG_CHECK_ARG(vg_aligned16(d->Wd) && vg_aligned16(d->Nr) && vg_aligned16(d->ws), VG_EALIGN);
+    VG_CHECK_ARG(d->ws_bytes >= p.ws_bytes, VG_EINVAL);
+    hipStream_t s = vg_stream(stream);
+    if (p.CT == 4) vg_launch_timed(1, edge_wgrad_kernel<4>, dim3(p.grid), dim3(256), 0, s, *d, p.R, p.tiles_per_img, p.ntiles, p.JT);
+    else vg_launch_timed(1, edge_wgrad_kernel<2>, dim3(p.grid), dim3(256), 0, s, *d, p.R, p.tiles_per_img, p.ntiles, p.JT);
+    rc = VG_LAUNCH_RC();
+    if (rc) return rc;
+    const int JC = p.JT * 16 * d->C;                                // multiple of 256 (C >= 32, J >= 48)
+    float* ws2 = d->ws + (int64_t)p.grid * JC;
+    hipLaunchKernelGGL(edge_wgrad_reduce1_kernel, dim3(JC / 256, EW_G), dim3(256), 0, s, d->ws, ws2, p.grid, JC);
+    hipLaunchKernelGGL(edge_wgrad_reduce2_kernel, dim3(JC / 256), dim3(256), 0, s, *d, ws2, p.JT * 16, d->C);
     return VG_LAUNCH_RC();
 }

@@ -185,6 +185,21 @@ class StackEngine:
             self._specs[key] = ok
         return self._specs[key]
 
+    def edge_wg(self, i: int, B: int):
+        """EWSpec when stage i's weight gradient runs on the edge-layer kernel (3-channel side: first Conv2d of D / E,
+        last ConvTranspose2d of G), else None."""
+        key = (i, B, "edge_wg")
+        if key not in self._specs:
+            st, sp = self.stages[i], None
+            if os.environ.get("VG_EDGE", "1") != "0" and os.environ.get("VG_EDGE_WGRAD", "1") != "0":
+                a = (B, st.hin, st.hin, st.cin, st.cout, st.k, st.s, st.p, self.dtype)
+                if st.kind == "conv" and st.cin <= 3 and G.padc(st.cin, self.dtype) == 8:
+                    sp = G.conv_wgrad_edge(*a)
+                elif st.kind == "convT" and st.cout <= 3 and G.padc(st.cout, self.dtype) == 8:
+                    sp = G.convT_wgrad_edge(*a)
+            self._specs[key] = sp
+        return self._specs[key]
+
     def tn(self, i: int, B: int, what: str):
         """(TNSpec, PackSpec) when stage i's `what` ('fprop' of a narrow ConvTranspose2d, 'dgrad' of a narrow Conv2d)
         runs on the edge-layer kernel (vg_tnconv) instead of the gather-GEMM, else None.  VG_EDGE=0 turns it off."""
@@ -532,7 +547,12 @@ class StackEngine:
                     g.copy_(src.view(g.shape))                 # contiguous device copy (hipMemcpyAsync), no ATen kernel
             return
         gw, acc = sink.get(st.conv.weight)
-        if st.kind == "conv":
+        ew = self.edge_wg(i, B)
+        if ew is not None and gw.is_contiguous():
+            # wide operand = the many-channel side, narrow = the 3-channel side (conv: dY / input image; convT: input / dY)
+            wide, narrow = (dY, c["x"]) if st.kind == "conv" else (c["x"], dY)
+            ops.edge_wgrad(ew, wide, narrow, gw, acc, alg=st.alg(B, dt))
+        elif st.kind == "conv":
             ops.wgrad(wg, dY, c["x"], gw, acc, dt, alg=st.alg(B, dt))
         else:
             ops.wgrad(wg, c["x"], dY, gw, acc, dt, alg=st.alg(B, dt))

@@ -200,6 +200,39 @@ def conv_dgrad_tn(B, H, W, Cin, Cout, k, s, p, dtype):
     return tn_spec(B, OH, OW, Cout, Cin, k, s, p, dtype, s_n=k * k, s_c=Cin * k * k)
 
 
+@dataclass
+class EWSpec:
+    """vg_edge_wgrad (csrc/edge_conv.hip): wide operand [B][WH][WW][C], narrow operand [B][NH][NW][8] (N real channels)."""
+    B: int; WH: int; WW: int; C: int; NH: int; NW: int; N: int; K: int; S: int; P: int; s_c: int; s_n: int
+
+    def flops(self) -> int:
+        return 2 * self.B * self.WH * self.WW * self.C * self.N * self.K * self.K
+
+
+def edge_wgrad_spec(B, wh, ww, C, nh, nw, N, k, s, p, dtype, s_c, s_n):
+    """-> EWSpec or None when the edge-layer weight-gradient kernel does not take the shape."""
+    if dtype != BF16 or C not in (32, 64) or N > 3 or k not in (3, 4) or s not in (1, 2) or ww > 256:
+        return None
+    R = 256 // ww
+    while R > 1 and (((R - 1) * s + k) * ((ww - 1) * s + k) + 1) * 16 > 22 * 1024:
+        R -= 1
+    if (((R - 1) * s + k) * ((ww - 1) * s + k) + 1) * 16 > 22 * 1024:
+        return None
+    return EWSpec(B=B, WH=wh, WW=ww, C=C, NH=nh, NW=nw, N=N, K=k, S=s, P=p, s_c=s_c, s_n=s_n)
+
+
+def conv_wgrad_edge(B, H, W, Cin, Cout, k, s, p, dtype):
+    """nn.Conv2d(Cin <= 3, Cout): wide = dY [B,OH,OW,Cout], narrow = the input image; dW [Cout][Cin][k][k]."""
+    OH, OW = conv_out(H, k, s, p), conv_out(W, k, s, p)
+    return edge_wgrad_spec(B, OH, OW, Cout, H, W, Cin, k, s, p, dtype, s_c=Cin * k * k, s_n=k * k)
+
+
+def convT_wgrad_edge(B, H, W, Cin, Cout, k, s, p, dtype):
+    """nn.ConvTranspose2d(Cin, Cout <= 3): wide = the input [B,H,W,Cin], narrow = dY [B,OH,OW,8]; dW [Cin][Cout][k][k]."""
+    OH, OW = convT_out(H, k, s, p), convT_out(W, k, s, p)
+    return edge_wgrad_spec(B, H, W, Cin, OH, OW, Cout, k, s, p, dtype, s_c=Cout * k * k, s_n=k * k)
+
+
 # ---- nn.Conv2d(Cin, Cout, k, s, p): weight [Cout][Cin][k][k] ---------------------------------------
 def conv_fprop(B, H, W, Cin, Cout, k, s, p, dtype):
     return _direct(B, H, W, Cin, Cout, k, s, p, dtype, s_n=Cin * k * k, s_c=k * k)

@@ -9,7 +9,7 @@ from ctypes import byref, c_int
 import torch
 
 from . import _lib as L
-from .geometry import BF16, F32, FP8, GGSpec, PackSpec, TNSpec, WGSpec, esize
+from .geometry import BF16, F32, FP8, EWSpec, GGSpec, PackSpec, TNSpec, WGSpec, esize
 
 TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16, FP8: torch.uint8}      # e4m3 bytes travel as uint8
 
@@ -330,6 +330,28 @@ def gather_gemm(g: GGSpec, X: torch.Tensor, Wp: torch.Tensor, dtype: int, bias: 
     if tok is not None:
         TIMER.end(tok)
     return Y, stats, nparts
+
+
+def edge_wgrad(ew: EWSpec, wide: torch.Tensor, narrow: torch.Tensor, dW: torch.Tensor, accumulate: bool, alg=None) -> None:
+    """Weight gradient of an edge layer (vg_edge_wgrad): wide [B,WH,WW,C] bf16, narrow [B,NH,NW,8] bf16, dW f32."""
+    _need_cuda(wide, narrow, dW)
+    if wide.dtype != torch.bfloat16 or narrow.dtype != torch.bfloat16 or dW.dtype != torch.float32:
+        raise RuntimeError("edge_wgrad: bf16 operands, float32 gradient")
+    if wide.numel() != ew.B * ew.WH * ew.WW * ew.C or narrow.numel() != ew.B * ew.NH * ew.NW * 8:
+        raise RuntimeError("edge_wgrad: operand size mismatch")
+    lib = L.load()
+    d = L.EWDesc(Wd=wide.data_ptr(), Nr=narrow.data_ptr(), dW=dW.data_ptr(), ws=0, ws_bytes=0,
+                 zeros=zero_page(wide.device).data_ptr(), B=ew.B, WH=ew.WH, WW=ew.WW, C=ew.C, NH=ew.NH, NW=ew.NW, N=ew.N,
+                 K=ew.K, S=ew.S, P=ew.P, s_c=ew.s_c, s_n=ew.s_n, accumulate=1 if accumulate else 0)
+    nbytes = lib.vg_edge_wgrad_ws_bytes(byref(d))
+    if nbytes < 0:
+        L.check(int(nbytes), "vg_edge_wgrad_ws_bytes")
+    ws = WS.get("wgrad" if _WS_SUFFIX is None else "wgrad" + _WS_SUFFIX, nbytes, wide.device)
+    d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * 4
+    tok = TIMER.begin("wgrad", *(alg or (ew.flops(), 0))) if TIMER is not None else None
+    L.check(lib.vg_edge_wgrad(byref(d), L.stream_ptr()), "vg_edge_wgrad")
+    if tok is not None:
+        TIMER.end(tok)
 
 
 def cast_fp8(x: torch.Tensor, shift: int = 0, out: torch.Tensor = None) -> torch.Tensor:
