@@ -16,13 +16,15 @@ import os
 import shutil
 import sys
 
-FAMILIES = {"gather_gemm": "gg_kernel", "wgrad": "wgrad_"}
+FAMILIES = {"gather_gemm": "gg_kernel", "wgrad": "wgrad_", "edge": "tnconv_kernel | ggn_kernel"}
 
 
 def fam_of(name):
     if "gg_kernel" in name or "ggp_kernel" in name:      # gather-GEMM and its patch variant (conv_patch.hpp)
         return "gather_gemm"
-    if "wgrad_" in name and "reduce" not in name and "dot_wgrad" not in name:   # wgrad_kernel<..>, wgrad_bf16[_dma]_kernel
+    if "tnconv_kernel" in name or "ggn_kernel" in name:  # edge layers (edge_conv.hip, conv_narrowk.hpp): HBM-bound
+        return "edge"
+    if "wgrad_" in name and "reduce" not in name and "dot_wgrad" not in name:   # wgrad_kernel<..>, wgrad_bf16[_dma]_kernel, edge_wgrad_kernel
         return "wgrad"
     return None
 
