@@ -52,17 +52,19 @@ __host__ __device__ inline int pack_tiles(const vg_pack_desc& d) {
 // One workgroup per tile over ALL descriptors of the table (flat grid: a 2-D (tile, descriptor) grid sized by the
 // largest layer launched ~50k workgroups of which most had nothing to do): descriptor i owns the flat tiles
 // [tile_start_i, tile_start_{i+1}); the owner of a tile is found with one load round + ballot over <= 64 entries.
+__device__ __forceinline__ int pk_sel4(const int32_t* a, int p) {      // a[p] for p < 4 without a memory round trip
+    return p == 0 ? a[0] : p == 1 ? a[1] : p == 2 ? a[2] : a[3];
+}
+
 template <int DT>
 __global__ __launch_bounds__(256) void pack_multi_kernel(const vg_pack_desc* __restrict__ descs, int ndesc) {
     __shared__ float tile[PK_NT][PK_CT][PK_TT + 1];
-    __shared__ int s_owner;
-    if (threadIdx.x < 64) {
-        const int ts = (int)threadIdx.x < ndesc ? descs[threadIdx.x].tile_start : 0x7fffffff;
-        const unsigned long long m = __ballot(ts <= (int)blockIdx.x);
-        if (threadIdx.x == 0) s_owner = __popcll(m) - 1;
-    }
-    __syncthreads();
-    const vg_pack_desc d = descs[s_owner];
+    // owner of this tile: every wave finds it by itself (one load round + ballot) and keeps it in an SGPR, so the
+    // descriptor fields below are scalar loads -- a workgroup is one short dependent chain (lookup -> descriptor ->
+    // source tile -> stores), and the launch is bound by the length of that chain, not by bytes
+    const int ts = (int)(threadIdx.x & 63) < ndesc ? descs[threadIdx.x & 63].tile_start : 0x7fffffff;
+    const int owner = __builtin_amdgcn_readfirstlane(__popcll(__ballot(ts <= (int)blockIdx.x)) - 1);
+    const vg_pack_desc d = descs[owner];
     const int rowsN = d.tap_in_n ? d.N / d.KHW : d.N;           // rows of the source "n" index
     const int ctiles = (d.IC + PK_CT - 1) / PK_CT;
     const int ntiles = (rowsN + PK_NT - 1) / PK_NT;
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const vg_pack_desc* __r
                     if (r >= rows) break;
                     const int p = r / T, t = r - p * T;
                     const int a = t / d.TW, b = t - a * d.TW;
-                    const int ft = (d.kh0[p] + d.kh_step * a) * d.KW + d.kw0[p] + d.kw_step * b - tap0;
+                    const int ft = (pk_sel4(d.kh0, p) + d.kh_step * a) * d.KW + pk_sel4(d.kw0, p) + d.kw_step * b - tap0;
                     if (ft < 0 || ft >= ntap) continue;
                     typename ElemT<DT>::type* q = reinterpret_cast<typename ElemT<DT>::type*>(d.dst) +
                                                   ((int64_t)p * d.N + n) * d.Kp + (int64_t)t * d.IC + cbase;
