@@ -20,8 +20,30 @@ namespace {
 
 constexpr int WG_BNP = 64, WG_BKQ = 64, WG_BMK = 32, WG_LD = 80;
 
+// XCD-aware workgroup order (cdna_hip_programming.md T1).  Workgroups are dealt round-robin over the 8 XCDs (private
+// L2 each) in launch order x, y, z.  Every tile (x, y) of one split z reads the SAME rows of P and the same region of
+// Q; with kq-tile counts that are multiples of 8 the plain order sends tile x to XCD x % 8, i.e. every XCD streams
+// ALL rows of P and (through its taps) all of Q: 8x the operand traffic out of the Infinity Cache (G4: 537 MB, 77 us
+// of loads for 37 us of MFMA).  Remapped, XCD k owns the k-th contiguous eighth of the (z, y, x) order: whole splits
+// (or whole np-rows of one), dispatched back to back, so the rows are fetched into one L2 once.  Speed only.
+struct WgTile { int x, y, z; };
+__device__ __forceinline__ WgTile wg_tile(int xcd_order) {
+    WgTile t = {(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
+    const int gx = gridDim.x, gy = gridDim.y, total = gx * gy * (int)gridDim.z;
+    if (xcd_order && (total & 7) == 0) {
+        const int id = t.x + gx * (t.y + gy * t.z);
+        const int l = (id & 7) * (total >> 3) + (id >> 3);
+        t.x = l % gx;
+        const int r = l / gx;
+        t.y = r % gy;
+        t.z = r / gy;
+    }
+    return t;
+}
+
+
 template <int DT>
-__global__ __launch_bounds__(256) void wgrad_kernel(const vg_wg_desc d, int rows_per_split, int KQ, int NPpad) {
+__global__ __launch_bounds__(256) void wgrad_kernel(const vg_wg_desc d, int rows_per_split, int KQ, int NPpad, int xcd_order) {
     typedef ElemT<DT> E;
     constexpr int ESZ = E::size;
     constexpr int P16 = E::per16;
@@ -32,11 +54,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const vg_wg_desc d, int rows
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wnp = wave >> 1, wkq = wave & 1;
-    const int kq0 = blockIdx.x * WG_BKQ;
-    const int np0 = blockIdx.y * WG_BNP;
+    const WgTile bt = wg_tile(xcd_order);
+    const int kq0 = bt.x * WG_BKQ;
+    const int np0 = bt.y * WG_BNP;
     const int M = d.B * d.GH * d.GW;
     const int GHW = d.GH * d.GW;
-    const int m_begin = blockIdx.z * rows_per_split;
+    const int m_begin = bt.z * rows_per_split;
     const int m_end = min(M, m_begin + rows_per_split);
 
     const int urow = tid / UPR;                   // row within a pass
@@ -134,7 +157,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const vg_wg_desc d, int rows
         __syncthreads();
     }
     // slab[split][np][kq]
-    float* slab = d.ws + (int64_t)blockIdx.z * NPpad * (int64_t)(gridDim.x * WG_BKQ);
+    float* slab = d.ws + (int64_t)bt.z * NPpad * (int64_t)(gridDim.x * WG_BKQ);
     const int ldk = gridDim.x * WG_BKQ;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -175,17 +198,18 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* tile, int krow0, 
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-__global__ __launch_bounds__(256) void wgrad_bf16_kernel(const vg_wg_desc d, int rows_per_split, int KQ, int NPpad) {
+__global__ __launch_bounds__(256) void wgrad_bf16_kernel(const vg_wg_desc d, int rows_per_split, int KQ, int NPpad, int xcd_order) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][WB_SM * WB_PITCH];   // [buf][P|Q]
     __shared__ int rowtab[2][WB_SM][3];                                                    // img base, iy0, ix0
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wnp = wave >> 1, wkq = wave & 1;
-    const int kq0 = blockIdx.x * WB_T;
-    const int np0 = blockIdx.y * WB_T;
+    const WgTile bt = wg_tile(xcd_order);
+    const int kq0 = bt.x * WB_T;
+    const int np0 = bt.y * WB_T;
     const int M = d.B * d.GH * d.GW;
     const int GHW = d.GH * d.GW;
-    const int m_begin = blockIdx.z * rows_per_split;
+    const int m_begin = bt.z * rows_per_split;
     const int m_end = min(M, m_begin + rows_per_split);
 
     const int unit = tid & 15;                     // 16-byte unit (8 bf16) within the 128-column tile row
@@ -282,7 +306,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const vg_wg_desc d, int
         if (s + 2 < nstage) fill_table(buf, m_begin + (s + 2) * WB_SM);            // table[buf] no longer needed
         __syncthreads();
     }
-    float* slab = d.ws + (int64_t)blockIdx.z * NPpad * (int64_t)(gridDim.x * WB_T);
+    float* slab = d.ws + (int64_t)bt.z * NPpad * (int64_t)(gridDim.x * WB_T);
     const int ldk = gridDim.x * WB_T;
     const int fi = lane & 15, fk = lane >> 4;
 #pragma unroll
@@ -319,7 +343,7 @@ constexpr int WD_SM = VG_WD_SM, WD_NBUF = VG_WD_NBUF, WD_STAGE = 2 * WD_SM * WB_
 
 #define WG_WAITCNT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 
-__global__ __launch_bounds__(256) void wgrad_bf16_dma_kernel(const vg_wg_desc d, int rows_per_split, int KQ, int NPpad) {
+__global__ __launch_bounds__(256) void wgrad_bf16_dma_kernel(const vg_wg_desc d, int rows_per_split, int KQ, int NPpad, int xcd_order) {
     // one shared object: [ring of stages][row tables: 4 x 32 x {image base, iy0, ix0}]
     __shared__ __attribute__((aligned(16))) unsigned char smem[WD_NBUF * WD_STAGE + 4 * WD_SM * 3 * 4];
     int* const rowtab = reinterpret_cast<int*>(smem + WD_NBUF * WD_STAGE);
@@ -327,11 +351,12 @@ __global__ __launch_bounds__(256) void wgrad_bf16_dma_kernel(const vg_wg_desc d,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int wnp = wave >> 1, wkq = wave & 1;
-    const int kq0 = blockIdx.x * WB_T;
-    const int np0 = blockIdx.y * WB_T;
+    const WgTile bt = wg_tile(xcd_order);
+    const int kq0 = bt.x * WB_T;
+    const int np0 = bt.y * WB_T;
     const int M = d.B * d.GH * d.GW;
     const int GHW = d.GH * d.GW;
-    const int m_begin = blockIdx.z * rows_per_split;
+    const int m_begin = bt.z * rows_per_split;
     const int m_end = min(M, m_begin + rows_per_split);
 
     const int rsub = lane >> 4;                              // row within the 4-row group of one DMA instruction
@@ -437,7 +462,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_dma_kernel(const vg_wg_desc d,
         wb = wb == WD_NBUF - 1 ? 0 : wb + 1;
     }
     static_assert(WD_NBUF >= 2 && WD_NBUF <= 4 && (LDMA == 4 || LDMA == 8), "vmcnt literals above");
-    float* slab = d.ws + (int64_t)blockIdx.z * NPpad * (int64_t)(gridDim.x * WB_T);
+    float* slab = d.ws + (int64_t)bt.z * NPpad * (int64_t)(gridDim.x * WB_T);
     const int ldk = gridDim.x * WB_T;
     const int fi = lane & 15, fk = lane >> 4;
 #pragma unroll
@@ -671,12 +696,17 @@ extern "C" int vg_wgrad(const vg_wg_desc* d, int dtype, void* stream) {
     VG_CHECK_ARG(d->ws_bytes >= p.ws_bytes, VG_EINVAL);
     hipStream_t s = vg_stream(stream);
     dim3 grid(p.tiles_kq, p.tiles_np, p.nsplit);
+    // XCD-aware order (wg_tile) where it pays: few tiles per split, many splits, long operands (measured S=64 B=128:
+    // G4 81 -> 55 us, D1 2B 44 -> 31, D1 26 -> 21, G3 55 -> 54; layers with >= 128 tiles per split lose 2-3 us)
+    static const int xcd_env = [] { const char* e = getenv("VG_WG_XCD"); return e ? atoi(e) : 1; }();
+    const int64_t Mrows = (int64_t)d->B * d->GH * d->GW;
+    const int xcd_order = xcd_env == 2 || (xcd_env == 1 && p.tiles_kq * p.tiles_np <= 32 && p.nsplit >= 16 && Mrows >= 32768);
     if (dtype == VG_F32)
-        vg_launch_timed(1, wgrad_kernel<VG_F32>, grid, dim3(256), 0, s, *d, p.rows_per_split, p.KQ, p.NPpad);
+        vg_launch_timed(1, wgrad_kernel<VG_F32>, grid, dim3(256), 0, s, *d, p.rows_per_split, p.KQ, p.NPpad, xcd_order);
     else if (wg_use_dma(d))
-        vg_launch_timed(1, wgrad_bf16_dma_kernel, grid, dim3(256), 0, s, *d, p.rows_per_split, p.KQ, p.NPpad);
+        vg_launch_timed(1, wgrad_bf16_dma_kernel, grid, dim3(256), 0, s, *d, p.rows_per_split, p.KQ, p.NPpad, xcd_order);
     else
-        vg_launch_timed(1, wgrad_bf16_kernel, grid, dim3(256), 0, s, *d, p.rows_per_split, p.KQ, p.NPpad);
+        vg_launch_timed(1, wgrad_bf16_kernel, grid, dim3(256), 0, s, *d, p.rows_per_split, p.KQ, p.NPpad, xcd_order);
     rc = VG_LAUNCH_RC();
     if (rc) return rc;
     // weight-heavy layers with few splits: streaming transpose-reduce (one contiguous run of dW per block)
