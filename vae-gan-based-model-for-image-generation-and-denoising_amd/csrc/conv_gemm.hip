@@ -91,6 +91,8 @@ struct DmaRing {
 #endif
 };
 
+constexpr int GG_N_MAJOR = 1 << 16;     // ksplit_arg flag of a non-split launch: XCD-major over n tiles
+
 template <int DT, int BM, int BN, int WM, int WN, bool SPLITK, bool DMA>
 __global__ __launch_bounds__(256) void gg_kernel(const vg_gg_desc d, const int ksplit_arg, const int stages_per_split) {
     const int ksplit = SPLITK ? ksplit_arg : 1;        // compile-time 1 on the common path (keeps its registers lean)
@@ -133,8 +135,16 @@ __global__ __launch_bounds__(256) void gg_kernel(const vg_gg_desc d, const int k
         const int n_tiles = (d.N + BN - 1) / BN;
         const int id = blockIdx.x;
         const int xcd = id & 7, slot = id >> 3;
-        by = slot % n_tiles;
-        bx = (slot / n_tiles) * 8 + xcd;
+        if (!SPLITK && (ksplit_arg & GG_N_MAJOR)) {
+            // weights larger than the input (n_major() below): an XCD owns n tiles (n % 8 == xcd) and walks all m
+            // tiles of one before the next, so it streams 1/8 of the WEIGHTS and all of the (smaller) input
+            const int mt = (int)gridDim.x / n_tiles;
+            bx = slot % mt;
+            by = (slot / mt) * 8 + xcd;
+        } else {
+            by = slot % n_tiles;
+            bx = (slot / n_tiles) * 8 + xcd;
+        }
     }
     const int m_tiles_ = (d.B * d.GH * d.GW + BM - 1) / BM;
     if (bx >= m_tiles_) return;                             // padding blocks of the last group of 8 m tiles
@@ -764,6 +774,18 @@ inline SplitK plan_splitk(const vg_gg_desc* d, int dtype, TileCfg t) {
     return r;
 }
 
+// Which operand an XCD keeps to itself.  Default: m tiles are dealt over the XCDs (each streams 1/8 of the gathered
+// input and ALL weights).  Where the weights are the larger operand (Generator stage 1: 16.8 MB of weights against
+// 4-8 MB of activations at B = 128) dealing the n tiles instead moves 8x less weight traffic out of the Infinity
+// Cache.  VG_GG_NMAJOR=0 turns it off.
+inline bool n_major(const vg_gg_desc* d, int n_tiles, int esz) {
+    static const int mode = [] { const char* e = getenv("VG_GG_NMAJOR"); return e ? atoi(e) : 1; }();
+    if (mode == 0 || n_tiles % 8 != 0) return false;
+    const int64_t wbytes = (int64_t)d->nphase * d->N * d->Kp * esz;
+    const int64_t abytes = (int64_t)d->B * d->IH * d->IW * d->IC * esz;
+    return mode == 2 || wbytes > abytes;
+}
+
 template <int DT, int BM, int BN, int WM, int WN>
 int launch(const vg_gg_desc* d, hipStream_t s, SplitK sk) {
     const int M = d->B * d->GH * d->GW;
@@ -771,20 +793,21 @@ int launch(const vg_gg_desc* d, hipStream_t s, SplitK sk) {
     const int m_tiles = (M + BM - 1) / BM, n_tiles = (d->N + BN - 1) / BN;
     dim3 grid(((m_tiles + 7) / 8) * 8 * n_tiles, 1, split ? sk.ksplit : d->nphase);
     const int nstages_all = 1 << 30;
+    const int one = 1 | (n_major(d, n_tiles, ElemT<DT>::size) ? GG_N_MAJOR : 0);
     constexpr bool CAN_DMA = (DT == VG_BF16 || DT == VG_FP8) && (BN % 64 == 0);
     const bool dma = CAN_DMA && use_dma() && d->zeros != nullptr;
     if constexpr (DT == VG_FP8) {
         // LDS-DMA ring as the bf16 kernel (the staging code is byte-generic: a 64-byte chunk holds 64 e4m3 channels)
-        if (dma) vg_launch_timed(3, gg_kernel<DT, BM, BN, WM, WN, false, true>, grid, dim3(256), 0, s, *d, 1, nstages_all);
-        else vg_launch_timed(3, gg_kernel<DT, BM, BN, WM, WN, false, false>, grid, dim3(256), 0, s, *d, 1, nstages_all);
+        if (dma) vg_launch_timed(3, gg_kernel<DT, BM, BN, WM, WN, false, true>, grid, dim3(256), 0, s, *d, one, nstages_all);
+        else vg_launch_timed(3, gg_kernel<DT, BM, BN, WM, WN, false, false>, grid, dim3(256), 0, s, *d, one, nstages_all);
         return VG_LAUNCH_RC();
     } else if (split) {
         vg_launch_timed(0, gg_kernel<DT, BM, BN, WM, WN, true, false>, grid, dim3(256), 0, s, *d, sk.ksplit, sk.sps);
     } else if constexpr (CAN_DMA) {
-        if (dma) vg_launch_timed(0, gg_kernel<DT, BM, BN, WM, WN, false, true>, grid, dim3(256), 0, s, *d, 1, nstages_all);
-        else vg_launch_timed(0, gg_kernel<DT, BM, BN, WM, WN, false, false>, grid, dim3(256), 0, s, *d, 1, nstages_all);
+        if (dma) vg_launch_timed(0, gg_kernel<DT, BM, BN, WM, WN, false, true>, grid, dim3(256), 0, s, *d, one, nstages_all);
+        else vg_launch_timed(0, gg_kernel<DT, BM, BN, WM, WN, false, false>, grid, dim3(256), 0, s, *d, one, nstages_all);
     } else {
-        vg_launch_timed(DT == VG_FP8 ? 3 : 0, gg_kernel<DT, BM, BN, WM, WN, false, false>, grid, dim3(256), 0, s, *d, 1, nstages_all);
+        vg_launch_timed(DT == VG_FP8 ? 3 : 0, gg_kernel<DT, BM, BN, WM, WN, false, false>, grid, dim3(256), 0, s, *d, one, nstages_all);
     }
     int rc = VG_LAUNCH_RC();
     if (rc || !split) return rc;
@@ -853,6 +876,7 @@ extern "C" int vg_gather_gemm(const vg_gg_desc* d, int dtype, void* stream) {
         use_patch() && use_dma() && d->zeros != nullptr && patch_geometry(d, t.bm, &pg)) {
         const int m_tiles = (d->B * d->GH * d->GW) / t.bm, n_tiles = (d->N + t.bn - 1) / t.bn;
         dim3 grid(((m_tiles + 7) / 8) * 8 * n_tiles, 1, d->nphase);
+        pg.n_major = n_major(d, n_tiles, 2) ? 1 : 0;
         if (t.bm == 256 && t.bn == 64) vg_launch_timed(0, (ggp_kernel<4, 64>), grid, dim3(512), 0, vg_stream(stream), *d, pg);
         else if (t.bm == 256) vg_launch_timed(0, ggp_kernel<4>, grid, dim3(512), 0, vg_stream(stream), *d, pg);
         else if (t.bn == 64) vg_launch_timed(0, (ggp_kernel<2, 64>), grid, dim3(256), 0, vg_stream(stream), *d, pg);

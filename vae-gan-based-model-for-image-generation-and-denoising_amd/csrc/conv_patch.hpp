@@ -22,6 +22,7 @@
 struct PatchGeo {
     int R, IMGS, PW, PIMG, NPP;     // grid rows per image in a tile, images per tile, patch width, pixels per image, total
     int ncy, ncx, nct;              // parity classes per dimension, 32-channel chunks per (class, tap)
+    int n_major;                    // XCD-major over n tiles (conv_gemm.hip n_major())
 };
 
 // Taps per barrier stage / weight-ring slots: 1 tap x 3 slots (48.5 KB, 3 workgroups per CU) or 2 taps x 2 slots
@@ -74,8 +75,14 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 2 : 1) void ggp_kernel(const vg
         const int n_tiles = (d.N + BN - 1) / BN;
         const int id = blockIdx.x;
         const int xcd = id & 7, slot = id >> 3;
-        by = slot % n_tiles;
-        bx = (slot / n_tiles) * 8 + xcd;
+        if (g.n_major) {
+            const int mt = (int)gridDim.x / n_tiles;
+            bx = slot % mt;
+            by = (slot / mt) * 8 + xcd;
+        } else {
+            by = slot % n_tiles;
+            bx = (slot / n_tiles) * 8 + xcd;
+        }
     }
     const int M = d.B * d.GH * d.GW;
     const int GHW = d.GH * d.GW;
