@@ -475,7 +475,11 @@ __global__ __launch_bounds__(256) void wgrad_bf16_dma_kernel(const vg_wg_desc d,
                 const int kq = kq0 + wkq * 64 + j * 16 + fi;
                 // the reduce kernel never reads the padding of a partly used tile (narrow layers: 3-channel
                 // image operands, 32/64-channel outputs): do not spend slab bandwidth on it
+#ifdef VG_ABL_NO_EPI
+                if (np < d.NP && kq < KQ && acc[i][j][r] == 123.456f) slab[(int64_t)np * ldk + kq] = acc[i][j][r];
+#else
                 if (np < d.NP && kq < KQ) slab[(int64_t)np * ldk + kq] = acc[i][j][r];
+#endif
             }
 }
 
