@@ -153,6 +153,10 @@ class StackEngine:
         # a high-priority main stream 17.5k): the concurrent wgrad and dgrad grids evict each other's L2/LDS
         # residency and the small kernels queue behind full CUs.  Kept as an opt-in experiment (VG_SIDE_WGRAD=1).
         self.side_wgrad = os.environ.get("VG_SIDE_WGRAD", "0") == "1"
+        # VG_SIDE_WGRAD=2: the same idea with a join per stage -- stage i's weight gradient is forked AFTER its data
+        # gradient and joined before the NEXT data gradient, so it runs beside the BatchNorm-backward chain of stage
+        # i-1 only and two GEMM-class grids never share the chip.
+        self.wgrad_under_bn = os.environ.get("VG_SIDE_WGRAD", "0") == "2"
 
     # ---- geometry (cached per batch size) -----------------------------------------------------
     def spec(self, i: int, B: int, what: str):
@@ -456,8 +460,20 @@ class StackEngine:
         dt = self.dtype
         dA = dout
         side = side_stream(dout.device) if (self.side_wgrad and param_grads) else None
+        fj = side_stream(dout.device) if (self.wgrad_under_bn and param_grads and defer is None) else None
+        forked = None                       # stage whose parameter gradients are in flight on the fork/join stream
         held = []                           # tensors the side stream reads: kept alive until the join
         masked = False                      # dA already carries the activation backward of the stage it belongs to
+
+        def join_forked():
+            nonlocal forked
+            if forked is not None:
+                torch.cuda.current_stream().wait_stream(fj)
+                held.clear()
+                if on_grads is not None:
+                    on_grads(forked)
+                forked = None
+
         for i in range(len(self.stages) - 1, -1, -1):
             st, c = self.stages[i], ctx[i]
             want_dx = need_dx or i > 0
@@ -488,8 +504,13 @@ class StackEngine:
             else:
                 dY = dA                                     # no activation, or its backward was fused into the dgrad above
             masked = False
+            fork_here = fj is not None and want_dx and i > 0
+            if fj is not None:
+                join_forked()               # stage i+1's parameter gradients ran beside this stage's BatchNorm backward
             if param_grads and defer is not None:
                 defer.append(lambda i=i, st=st, c=c, dY=dY, rows=rows, OC=OC: self._param_grads(i, st, c, dY, B, rows, OC, sink))
+            elif param_grads and fork_here:
+                pass                        # launched below, after this stage's data gradient
             elif param_grads:
                 if side is None:
                     self._param_grads(i, st, c, dY, B, rows, OC, sink)
@@ -518,6 +539,14 @@ class StackEngine:
                 dA = dX.view(c["x"].shape)
             else:
                 dA = None
+            if param_grads and defer is None and fork_here:
+                fj.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(fj):
+                    self._param_grads(i, st, c, dY, B, rows, OC, sink)
+                held.append(dY)
+                forked = i
+        if fj is not None:
+            join_forked()
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
             held.clear()
