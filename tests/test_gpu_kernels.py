@@ -558,3 +558,55 @@ def test_patch_gather_gemm_equals_reference_and_gather_path(ops, monkeypatch, ki
     # same products, different summation order (class/chunk/tap instead of tap/chunk): bf16 output rounding apart
     close(outs[variant][0], outs["gather"][0], dtype)
     torch.testing.assert_close(outs[variant][1], outs["gather"][1], rtol=1e-5, atol=1e-3)
+
+
+# ---- weight-stationary persistent gather-GEMM (csrc/conv_stationary.hpp): short-K transposed forms, N = 64 ----------
+STATIONARY_CASES = [  # kind, B, H (input), Cin, Cout
+    ("convT", 32, 32, 128, 64),        # the Generator's ConvTranspose2d(128 -> 64) shape class (gan_code.py:42): 3-round patches
+    ("conv_dgrad", 32, 64, 64, 128),   # data gradient of the Discriminator's Conv2d(64 -> 128) (gan_code.py:66)
+    ("convT", 8, 64, 64, 64),          # 64-wide grid: 4-round patches, 2 chunks
+    ("convT", 8, 64, 32, 64),          # one chunk per tile
+    ("convT", 40, 32, 96, 64),         # tiles per phase not a power of two (320 = 64 workgroups x 5 tiles), 3 chunks
+]
+
+
+@pytest.mark.parametrize("kind,B,H,Cin,Cout", STATIONARY_CASES)
+def test_stationary_gather_gemm_equals_reference_and_patch_path(ops, monkeypatch, kind, B, H, Cin, Cout):
+    """ggs_kernel (weights resident in LDS, persistent over M tiles, patch ring with counted vmcnt) against torch fp64
+    and against the one-tile-per-workgroup patch kernel; BatchNorm partial sums: one slab row per workgroup."""
+    dtype = G.BF16
+    g = torch.Generator().manual_seed(H * 5 + Cin)
+    if kind == "convT":
+        x = _q(torch.randn(B, Cin, H, H, generator=g), dtype)
+        w = torch.randn(Cin, Cout, 4, 4, generator=g) * 0.1
+        ref = F.conv_transpose2d(x, _q(w, dtype), None, stride=2, padding=1)
+        gg, pk = G.convT_fprop(B, H, H, Cin, Cout, 4, 2, 1, dtype)
+        nout = Cout
+    else:
+        x = _q(torch.randn(B, Cout, H // 2, H // 2, generator=g), dtype)
+        w = torch.randn(Cout, Cin, 4, 4, generator=g) * 0.1
+        ref = torch.nn.grad.conv2d_input((B, Cin, H, H), _q(w, dtype), x, stride=2, padding=1)
+        gg, pk = G.conv_dgrad(B, H, H, Cin, Cout, 4, 2, 1, dtype)
+        nout = Cin
+    assert nout == 64
+    Wp = ops.pack_weights(pk, w.to(DEV), dtype)
+    X = _dev(to_nhwc(x, gg.IC), dtype, ops)
+    M = gg.B * gg.GH * gg.GW
+    outs = {}
+    for mode in ("patch", "stationary"):
+        monkeypatch.setenv("VG_GG_STATIONARY", "1" if mode == "stationary" else "0")
+        Y, st, nparts = ops.gather_gemm(gg, X, Wp, dtype, want_stats=True)
+        if mode == "stationary":
+            assert nparts <= 256 and (M // 128) % (nparts // gg.nphase) == 0, nparts       # one slab row per workgroup
+            assert ops.gather_gemm_tile_m(gg, X, Wp, dtype) == (M // 128) // (nparts // gg.nphase) * 128
+        else:
+            assert nparts == gg.nphase * (M // 128)
+        outs[mode] = (from_nhwc(Y.double().cpu(), nout), st[: nparts * 2 * nout].view(nparts, 2, nout).double().sum(0).cpu())
+    close(outs["stationary"][0], ref, dtype)
+    assert torch.equal(outs["stationary"][0], outs["patch"][0])      # same products in the same order (chunk, tap)
+    torch.testing.assert_close(outs["stationary"][1], outs["patch"][1], rtol=1e-5, atol=1e-2)
+    # a second call on a dirty output buffer: nothing is left unwritten
+    monkeypatch.setenv("VG_GG_STATIONARY", "1")
+    Y2, _, _ = ops.gather_gemm(gg, X, Wp, dtype, bias=torch.full((64,), 0.5, device=DEV), act=(2, 0.2))
+    ref2 = F.leaky_relu(ref + 0.5, 0.2)
+    close(from_nhwc(Y2.double().cpu(), nout), ref2, dtype)

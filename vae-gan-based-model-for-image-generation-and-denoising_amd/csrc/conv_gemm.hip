@@ -688,6 +688,8 @@ inline bool use_dma() {
     return v != 0;
 }
 
+#include "conv_stationary.hpp"
+
 inline int min_wgs() {                      // read per call (a few hundred ns): tests flip it inside one process
     const char* e = getenv("VG_TILE_MIN_WGS");
     return e ? atoi(e) : 512;
@@ -836,6 +838,9 @@ int dispatch(const vg_gg_desc* d, TileCfg t, hipStream_t s, SplitK sk) {
 extern "C" int vg_gather_gemm_nparts(const vg_gg_desc* d, int dtype) {
     int rc = validate(d, dtype);
     if (rc) return rc;
+    PatchGeo pg;
+    StatPlan sp;
+    if (stationary_plan(d, dtype, &pg, &sp)) return d->nphase * sp.wgs_per_phase;     // one slab row per workgroup
     TileCfg t = pick_tile(d, dtype == VG_BF16, dtype == VG_FP8);
     const int M = d->B * d->GH * d->GW;
     return d->nphase * ((M + t.bm - 1) / t.bm);
@@ -850,6 +855,9 @@ extern "C" int vg_gather_gemm_family(const vg_gg_desc* d, int dtype) {
 extern "C" int vg_gather_gemm_tile_m(const vg_gg_desc* d, int dtype) {
     int rc = validate(d, dtype);
     if (rc) return rc;
+    PatchGeo pg;
+    StatPlan sp;
+    if (stationary_plan(d, dtype, &pg, &sp)) return sp.tiles_per_wg * GS_BM;          // rows behind one slab row
     return pick_tile(d, dtype == VG_BF16, dtype == VG_FP8).bm;
 }
 
@@ -862,6 +870,12 @@ extern "C" int64_t vg_gather_gemm_ws_bytes(const vg_gg_desc* d, int dtype) {
 extern "C" int vg_gather_gemm(const vg_gg_desc* d, int dtype, void* stream) {
     int rc = validate(d, dtype);
     if (rc) return rc;
+    PatchGeo pg;
+    StatPlan sp;
+    if (stationary_plan(d, dtype, &pg, &sp)) {                  // short-K transposed forms: weights resident in LDS
+        if (d->stats) VG_CHECK_ARG(d->stats_capacity >= d->nphase * sp.wgs_per_phase, VG_EINVAL);
+        return launch_stationary(d, pg, sp, vg_stream(stream));
+    }
     TileCfg t = pick_tile(d, dtype == VG_BF16, dtype == VG_FP8);
     const SplitK sk = plan_splitk(d, dtype, t);
     if (d->stats) {
@@ -871,7 +885,6 @@ extern "C" int vg_gather_gemm(const vg_gg_desc* d, int dtype, void* stream) {
     if (dtype == VG_F32) return dispatch<VG_F32>(d, t, vg_stream(stream), sk);
     if (dtype == VG_FP8) return dispatch<VG_FP8>(d, t, vg_stream(stream), sk);
     if (narrowk_ok(d, dtype)) return launch_narrowk(d, vg_stream(stream));
-    PatchGeo pg;
     if ((t.bm == 128 || t.bm == 256) && (t.bn == GP_BN || (t.bn == 64 && patch64())) && sk.ksplit <= 1 &&
         use_patch() && use_dma() && d->zeros != nullptr && patch_geometry(d, t.bm, &pg)) {
         const int m_tiles = (d->B * d->GH * d->GW) / t.bm, n_tiles = (d->N + t.bn - 1) / t.bn;
