@@ -115,6 +115,10 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 2 : 1) void ggp_kernel(const vg
     }
     // ---- patch DMA lanes: LDS slot sidx = NT*r + tid -> pixel pp = sidx >> 2, stored unit sidx & 3.  The lane's
     // pixel coordinates are recomputed at every class change (<= 4 times per kernel) rather than kept in registers.
+    // Unit swizzle of the patch image: unit u of pixel pp sits in slot u ^ ((pp >> 1) & 3).  The four taps read the
+    // patch at offsets 0, 1, PW, PW + 1 (PW odd), so a fragment's 16 pixels start at ANY alignment; with this key a
+    // ds_read_b128 of 16 consecutive pixels is conflict-free at every offset (4 LDS cycles; the row-tile key
+    // (-(pp >> 2)) & 3 of gg_kernel cost 7.5-7.75 here: SQ_LDS_BANK_CONFLICT was 37-53 % of SQ_LDS_IDX_ACTIVE).
     const unsigned char* a_cur[NR];
     uint32_t a_live = 0;                                         // bit r: round r reads real data (else the zero page)
     auto patch_sources = [&](int cl) {
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 2 : 1) void ggp_kernel(const vg
         for (int r = 0; r < NR; ++r) {
             const int sidx = NT * r + tid;
             const int pp = sidx >> 2;
-            const int q = (sidx & 3) ^ ((-(pp >> 2)) & 3);
+            const int q = (sidx & 3) ^ ((pp >> 1) & 3);
             const int img = pp / g.PIMG;
             const int rem = pp - img * g.PIMG;
             const int pr = rem / g.PW;
@@ -214,7 +218,7 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 2 : 1) void ggp_kernel(const vg
         u32x4 fa[TM], fb[TN];
         auto ld_a = [&](int i) {
             const int pp = ppbase[i] + tapoff;
-            fa[i] = *reinterpret_cast<const u32x4*>(sa + pp * 64 + ((fg ^ ((-(pp >> 2)) & 3)) << 4));
+            fa[i] = *reinterpret_cast<const u32x4*>(sa + pp * 64 + ((fg ^ ((pp >> 1) & 3)) << 4));
         };
         auto ld_b = [&](int j) {
             const int r = wn * WNC + j * 16 + fr;

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(GS_NT) void ggs_kernel(const vg_gg_desc d, const Pa
     for (int r = 0; r < NR; ++r) {
         const int sidx = NT * r + tid;
         const int pp = sidx >> 2;
-        p_q16[r] = (uint32_t)(((sidx & 3) ^ ((-(pp >> 2)) & 3)) * 16);
+        p_q16[r] = (uint32_t)(((sidx & 3) ^ ((pp >> 1) & 3)) * 16);
         p_img[r] = pp / g.PIMG;
         const int rem = pp - p_img[r] * g.PIMG;
         p_pr[r] = rem / g.PW;
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(GS_NT) void ggs_kernel(const vg_gg_desc d, const Pa
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int pp = ppbase[i] + tapoff;
-            fa[i] = *reinterpret_cast<const u32x4*>(sa + pp * 64 + ((fg ^ ((-(pp >> 2)) & 3)) << 4));
+            fa[i] = *reinterpret_cast<const u32x4*>(sa + pp * 64 + ((fg ^ ((pp >> 1) & 3)) << 4));
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
