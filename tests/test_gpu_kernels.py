@@ -610,3 +610,39 @@ def test_stationary_gather_gemm_equals_reference_and_patch_path(ops, monkeypatch
     Y2, _, _ = ops.gather_gemm(gg, X, Wp, dtype, bias=torch.full((64,), 0.5, device=DEV), act=(2, 0.2))
     ref2 = F.leaky_relu(ref + 0.5, 0.2)
     close(from_nhwc(Y2.double().cpu(), nout), ref2, dtype)
+
+
+@pytest.mark.parametrize("kind,B,H,Cin,Cout", [("conv", 8, 16, 64, 128), ("convT", 8, 8, 128, 64), ("convT", 8, 1, 100, 1024),
+                                               ("conv", 3, 16, 32, 64)])
+def test_workgroup_order_switches_do_not_change_results(ops, monkeypatch, kind, B, H, Cin, Cout):
+    """The XCD-aware workgroup orders (wgrad: VG_WG_XCD, gather-GEMM: VG_GG_NMAJOR) are pure placement: forced on for
+    every launch (=2) and off (=0) must give bit-identical outputs, also where the grid is not a multiple of 8."""
+    dtype = G.BF16
+    g = torch.Generator().manual_seed(B + H + Cin)
+    k, s, p = (4, 1, 0) if H == 1 else (4, 2, 1)
+    a = (B, H, H, Cin, Cout, k, s, p, dtype)
+    if kind == "conv":
+        gg, pk = G.conv_fprop(*a)
+        ggd, pkd = G.conv_dgrad(*a)
+        wg = G.conv_wgrad(*a)
+        w = torch.randn(Cout, Cin, k, k, generator=g).to(DEV) * 0.1
+    else:
+        gg, pk = G.convT_fprop(*a)
+        ggd, pkd = G.convT_dgrad(*a)
+        wg = G.convT_wgrad(*a)
+        w = torch.randn(Cin, Cout, k, k, generator=g).to(DEV) * 0.1
+    X = torch.randn(gg.B, gg.IH, gg.IW, gg.IC, generator=g).to(DEV).to(torch.bfloat16)
+    DY = torch.randn(ggd.B, ggd.IH, ggd.IW, ggd.IC, generator=g).to(DEV).to(torch.bfloat16)
+    Wp, Wd = ops.pack_weights(pk, w, dtype), ops.pack_weights(pkd, w, dtype)
+    res = {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("VG_WG_XCD", mode)
+        monkeypatch.setenv("VG_GG_NMAJOR", mode)
+        Y, _, _ = ops.gather_gemm(gg, X, Wp, dtype)
+        DX, _, _ = ops.gather_gemm(ggd, DY, Wd, dtype)
+        dW = torch.zeros(w.shape, device=DEV)
+        P, Q = (X, DY) if kind == "convT" else (DY, X)
+        ops.wgrad(wg, P, Q, dW, False, dtype)
+        res[mode] = (Y.clone(), DX.clone(), dW)
+    for a_, b_ in zip(res["0"], res["2"]):
+        assert torch.equal(a_, b_)

@@ -781,7 +781,7 @@ inline SplitK plan_splitk(const vg_gg_desc* d, int dtype, TileCfg t) {
 // 4-8 MB of activations at B = 128) dealing the n tiles instead moves 8x less weight traffic out of the Infinity
 // Cache.  VG_GG_NMAJOR=0 turns it off.
 inline bool n_major(const vg_gg_desc* d, int n_tiles, int esz) {
-    static const int mode = [] { const char* e = getenv("VG_GG_NMAJOR"); return e ? atoi(e) : 1; }();
+    const int mode = [] { const char* e = getenv("VG_GG_NMAJOR"); return e ? atoi(e) : 1; }();        // per call: tests flip it
     if (mode == 0 || n_tiles % 8 != 0) return false;
     const int64_t wbytes = (int64_t)d->nphase * d->N * d->Kp * esz;
     const int64_t abytes = (int64_t)d->B * d->IH * d->IW * d->IC * esz;

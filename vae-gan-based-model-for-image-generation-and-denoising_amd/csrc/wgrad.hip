@@ -604,13 +604,24 @@ __global__ __launch_bounds__(256) void wgrad_reduce_t_kernel(const vg_wg_desc d,
             const float4 v = *reinterpret_cast<const float4*>(src + k * stride);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
-        float* tl = tile + (c4 * 4) * T + t;
+        // [cq][tap] image, 16 lanes (c4) write the same tap column of 16 different rows: with plain rows of T = 16
+        // floats that is ONE bank pair (SQ_LDS_BANK_CONFLICT was 91 % of this kernel's LDS cycles); the column is
+        // XOR-ed with the row's c4, which spreads a wave's write over 16 banks
+        const int sw = T == 16 ? c4 : 0;
+        float* tl = tile + (c4 * 4) * T + (t ^ sw);
         tl[0] = s.x; tl[T] = s.y; tl[2 * T] = s.z; tl[3 * T] = s.w;
     }
     __syncthreads();
     float* dst = d.dW + (int64_t)np * d.s_np + (int64_t)cq0 * T;
     for (int i = threadIdx.x * 4; i < 64 * T; i += 1024) {       // 64*T % 4 == 0; run start is 16-byte aligned (T*cq0 % 4 == 0)
-        float4 v = *reinterpret_cast<const float4*>(tile + i);
+        float4 v;
+        if (T == 16) {
+            const float* row = tile + (i & ~15);
+            const int key = (i >> 6) & 15, c = i & 15;           // row i/16 = cq, its c4 = cq >> 2
+            v.x = row[c ^ key]; v.y = row[(c + 1) ^ key]; v.z = row[(c + 2) ^ key]; v.w = row[(c + 3) ^ key];
+        } else {
+            v = *reinterpret_cast<const float4*>(tile + i);
+        }
         if (d.accumulate) {
             const float4 o = *reinterpret_cast<const float4*>(dst + i);
             v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
@@ -702,7 +713,7 @@ extern "C" int vg_wgrad(const vg_wg_desc* d, int dtype, void* stream) {
     dim3 grid(p.tiles_kq, p.tiles_np, p.nsplit);
     // XCD-aware order (wg_tile) where it pays: few tiles per split, many splits, long operands (measured S=64 B=128:
     // G4 81 -> 55 us, D1 2B 44 -> 31, D1 26 -> 21, G3 55 -> 54; layers with >= 128 tiles per split lose 2-3 us)
-    static const int xcd_env = [] { const char* e = getenv("VG_WG_XCD"); return e ? atoi(e) : 1; }();
+    const int xcd_env = [] { const char* e = getenv("VG_WG_XCD"); return e ? atoi(e) : 1; }();      // per call: tests flip it
     const int64_t Mrows = (int64_t)d->B * d->GH * d->GW;
     const int xcd_order = xcd_env == 2 || (xcd_env == 1 && p.tiles_kq * p.tiles_np <= 32 && p.nsplit >= 16 && Mrows >= 32768);
     if (dtype == VG_F32)
