@@ -398,19 +398,30 @@ __global__ __launch_bounds__(256) void wgrad_bf16_dma_kernel(const vg_wg_desc d,
 #endif
         unsigned char* sp = smem + buf * WD_STAGE;
         unsigned char* sq = sp + WD_SM * WB_PITCH;
+        // all row-table entries of this lane's rows FIRST (one LDS round trip; read next to their use they were two
+        // dependent LDS latencies in front of every Q instruction: ~1200 cycles per stage in which the wave issues
+        // neither DMA nor MFMA), then every source offset, then the DMA instructions back to back
+        int e0[WD_SM / 16], e1[WD_SM / 16], e2[WD_SM / 16];
 #pragma unroll
         for (int j = 0; j < WD_SM / 16; ++j) {
-            const int r = 16 * j + 4 * wave + rsub;
-            const int m = ms + r;
-            const int64_t offp = (p_ok && m < m_end) ? ((int64_t)m * d.PC + np0 + unit * 8) * 2 : zoffP;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Pb + offp),
+            const int* e = rowtab + (slot * WD_SM + 16 * j + 4 * wave + rsub) * 3;
+            e0[j] = e[0]; e1[j] = e[1]; e2[j] = e[2];
+        }
+        int64_t offp[WD_SM / 16], offq[WD_SM / 16];
+#pragma unroll
+        for (int j = 0; j < WD_SM / 16; ++j) {
+            const int m = ms + 16 * j + 4 * wave + rsub;
+            offp[j] = (p_ok && m < m_end) ? ((int64_t)m * d.PC + np0 + unit * 8) * 2 : zoffP;
+            const int iy = e1[j] + qdy, ix = e2[j] + qdx;
+            const bool ok = q_ok && (unsigned)iy < (unsigned)d.QH && (unsigned)ix < (unsigned)d.QW;
+            offq[j] = ok ? ((int64_t)(e0[j] + iy * d.QW + ix) * d.QC + cq) * 2 : zoffQ;
+        }
+#pragma unroll
+        for (int j = 0; j < WD_SM / 16; ++j) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Pb + offp[j]),
                                              (__attribute__((address_space(3))) void*)(sp + (16 * j + 4 * wave_u) * WB_PITCH),
                                              16, 0, 0);
-            const int* e = rowtab + (slot * WD_SM + r) * 3;
-            const int iy = e[1] + qdy, ix = e[2] + qdx;
-            const bool ok = q_ok && (unsigned)iy < (unsigned)d.QH && (unsigned)ix < (unsigned)d.QW;
-            const int64_t offq = ok ? ((int64_t)(e[0] + iy * d.QW + ix) * d.QC + cq) * 2 : zoffQ;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Qb + offq),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Qb + offq[j]),
                                              (__attribute__((address_space(3))) void*)(sq + (16 * j + 4 * wave_u) * WB_PITCH),
                                              16, 0, 0);
         }
@@ -480,6 +491,158 @@ __global__ __launch_bounds__(256) void wgrad_bf16_dma_kernel(const vg_wg_desc d,
 #else
                 if (np < d.NP && kq < KQ) slab[(int64_t)np * ldk + kq] = acc[i][j][r];
 #endif
+            }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Wave-specialised form of the LDS-DMA kernel (VG_WG_SPEC=1): the same 128 x 128 tile, LDS image, fragment reads and
+// slab epilogue, but the DMA is issued by EIGHT producer waves while FOUR consumer waves do nothing but transposed
+// fragment reads and MFMA.  Why: in the kernel above a wave issues its 8 global_load_lds of a stage in one burst
+// (60-185 cycles each, MI355X_MICROARCH.md) and only then its 32 MFMAs (512 cycles): the two phases add (ablations in
+// loads alone 28 us, arithmetic alone 30 us, together 55 us) and overlap only through the second
+// workgroup of the CU.  Here issue and arithmetic belong to different waves of ONE workgroup per CU (12 waves = 3 per
+// SIMD), a ring of three 32 KB stages keeps two stages in flight across the single s_barrier per stage, and a producer
+// wave issues 4 DMA instructions per stage (P and Q of row groups pw and pw + 8: (row & 7), the swizzle key, is the
+// same for both, so a lane still fetches one fixed source unit for the whole kernel).
+// MEASURED (S=64 B=128, tools/ab_wgrad_spec.sh; results identical to the kernel above, all wgrad tests pass under
+// VG_WG_SPEC=1): 3-8 % SLOWER -- G2 59.4 vs 55.1 us, G4 57.1 vs 55.0, D1 (2B) 33.3 vs 31.0.  With the DMA issue gone
+// from their instruction stream the four consumer waves (one per SIMD) still need ~1000 cycles per 64-row stage for
+// 512 cycles of MFMA: 16 transposed fragment reads, their latency, 16 MFMAs, twice per stage, and nothing on the SIMD to
+// fill the wait.  That is the same 50 % the two-workgroup kernel reaches with the loads switched off (30 us), so the
+// arithmetic side, not the overlap of issue and arithmetic, is what bounds both.  Kept opt-in as the starting point
+// for a consumer loop with fragment reads pipelined ACROSS the stage barrier.
+constexpr int WS_NBUF = 3, WS_NCONS = 4, WS_NPROD = 8, WS_NT = 64 * (WS_NCONS + WS_NPROD);
+
+__global__ __launch_bounds__(WS_NT) void wgrad_bf16_ws_kernel(const vg_wg_desc d, int rows_per_split, int KQ, int NPpad, int xcd_order) {
+    constexpr int STAGE = 2 * WD_SM * WB_PITCH;
+    static_assert(WD_SM == 64, "producer wave pw owns row groups pw and pw + 8 of a 64-row stage");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[WS_NBUF * STAGE + 4 * WD_SM * 3 * 4];
+    int* const rowtab = reinterpret_cast<int*>(smem + WS_NBUF * STAGE);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const bool producer = wave_u >= WS_NCONS;
+    const int pw = wave_u - WS_NCONS;                         // producer index 0..7 (negative for consumers)
+    const int wnp = (wave & 3) >> 1, wkq = wave & 1;          // consumers: 64 x 64 quadrant of the tile
+    const WgTile bt = wg_tile(xcd_order);
+    const int kq0 = bt.x * WB_T;
+    const int np0 = bt.y * WB_T;
+    const int M = d.B * d.GH * d.GW;
+    const int GHW = d.GH * d.GW;
+    const int m_begin = bt.z * rows_per_split;
+    const int m_end = min(M, m_begin + rows_per_split);
+    const int nstage = (m_end - m_begin + WD_SM - 1) / WD_SM;
+
+    if (producer) {
+        const int rsub = lane >> 4;                          // row within the 4-row group of one DMA instruction
+        const int upos = lane & 15;                          // 16-byte position within the 256-byte LDS row
+        const int key = (4 * pw + rsub) & 7;                 // row & 7 for both row groups of this wave
+        const int unit = (((upos >> 1) ^ key) << 1) | (upos & 1);
+        const int kq_e = kq0 + unit * 8;
+        const bool q_ok = kq_e < KQ;
+        const int t = q_ok ? kq_e / d.QC : 0;
+        const int cq = kq_e - t * d.QC;
+        const int ta = t / d.TW, tb = t - ta * d.TW;
+        const int qdy = d.DY * ta, qdx = d.DX * tb;
+        const bool p_ok = np0 + unit * 8 < d.PC;
+        const unsigned char* Pb = reinterpret_cast<const unsigned char*>(d.P);
+        const unsigned char* Qb = reinterpret_cast<const unsigned char*>(d.Q);
+        const int64_t zoffP = reinterpret_cast<const unsigned char*>(d.zeros) - Pb;
+        const int64_t zoffQ = reinterpret_cast<const unsigned char*>(d.zeros) - Qb;
+        const int ptid = tid - 64 * WS_NCONS;                // 0..511
+
+        auto fill_table = [&](int slot, int ms) {            // first producer wave: one row per lane
+            if (ptid < WD_SM) {
+                const int m = ms + ptid;
+                int base = 0, iy0 = -(1 << 28), ix0 = 0;
+                if (m < m_end) {
+                    const int b = m / GHW;
+                    const int r = m - b * GHW;
+                    const int gy = r / d.GW;
+                    const int gx = r - gy * d.GW;
+                    base = b * d.QH * d.QW;
+                    iy0 = gy * d.SY + d.y0;
+                    ix0 = gx * d.SX + d.x0;
+                }
+                int* e = rowtab + (slot * WD_SM + ptid) * 3;
+                e[0] = base; e[1] = iy0; e[2] = ix0;
+            }
+        };
+        auto issue_stage = [&](int buf, int slot, int ms) {
+            unsigned char* sp = smem + buf * STAGE;
+            unsigned char* sq = sp + WD_SM * WB_PITCH;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int rg = pw + 8 * jj;                  // row group (4 rows) of this instruction
+                const int r = 4 * rg + rsub;
+                const int m = ms + r;
+                const int64_t offp = (p_ok && m < m_end) ? ((int64_t)m * d.PC + np0 + unit * 8) * 2 : zoffP;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Pb + offp),
+                                                 (__attribute__((address_space(3))) void*)(sp + 4 * rg * WB_PITCH),
+                                                 16, 0, 0);
+                const int* e = rowtab + (slot * WD_SM + r) * 3;
+                const int iy = e[1] + qdy, ix = e[2] + qdx;
+                const bool ok = q_ok && (unsigned)iy < (unsigned)d.QH && (unsigned)ix < (unsigned)d.QW;
+                const int64_t offq = ok ? ((int64_t)(e[0] + iy * d.QW + ix) * d.QC + cq) * 2 : zoffQ;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Qb + offq),
+                                                 (__attribute__((address_space(3))) void*)(sq + 4 * rg * WB_PITCH),
+                                                 16, 0, 0);
+            }
+        };
+        // row tables of the first three stages, visible to all producer waves before the first issue
+#pragma unroll
+        for (int p = 0; p < WS_NBUF; ++p)
+            if (p < nstage) fill_table(p, m_begin + p * WD_SM);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                   // barrier P (all 12 waves)
+        if (nstage > 0) issue_stage(0, 0, m_begin);
+        if (nstage > 1) issue_stage(1, 1, m_begin + WD_SM);
+        for (int s = 0; s < nstage; ++s) {
+            // stage s has landed once at most the 4 instructions of stage s+1 are outstanding (in-order completion)
+            if (s + 1 < nstage) WG_WAITCNT_VM(4); else WG_WAITCNT_VM(0);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");               // barrier s: consumers may read s,
+            if (s + 2 < nstage) issue_stage((s + 2) % WS_NBUF, (s + 2) & 3, m_begin + (s + 2) * WD_SM);   // slot of s-1 is free
+            if (s + 3 < nstage) fill_table((s + 3) & 3, m_begin + (s + 3) * WD_SM);
+        }
+        return;
+    }
+
+    // ---------------- consumers ----------------
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_s_barrier();                                                          // barrier P
+    for (int s = 0; s < nstage; ++s) {
+        __builtin_amdgcn_s_barrier();                                                      // barrier s
+        const unsigned char* sp = smem + (s % WS_NBUF) * STAGE;
+        const unsigned char* sq = sp + WD_SM * WB_PITCH;
+#pragma unroll
+        for (int ks = 0; ks < WD_SM / 32; ++ks) {
+            bf16x8 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = tr_frag(sp, ks * 32, wnp * 64 + i * 16, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = tr_frag(sq, ks * 32, wkq * 64 + j * 16, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    const int ldk = gridDim.x * WB_T;
+    float* slab = d.ws + (int64_t)bt.z * NPpad * (int64_t)ldk;
+    const int fi = lane & 15, fk = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int np = np0 + wnp * 64 + i * 16 + fk * 4 + r;
+                const int kq = kq0 + wkq * 64 + j * 16 + fi;
+                if (np < d.NP && kq < KQ) slab[(int64_t)np * ldk + kq] = acc[i][j][r];
             }
 }
 
@@ -651,6 +814,11 @@ inline int wg_target() {
     return v;
 }
 
+inline bool wg_spec() {                     // per call: tests and A/B scripts flip it
+    const char* e = getenv("VG_WG_SPEC");
+    return e ? atoi(e) != 0 : false;
+}
+
 inline bool wg_use_dma(const vg_wg_desc* d) {
     static int v = -1;
     if (v < 0) {
@@ -718,6 +886,8 @@ extern "C" int vg_wgrad(const vg_wg_desc* d, int dtype, void* stream) {
     const int xcd_order = xcd_env == 2 || (xcd_env == 1 && p.tiles_kq * p.tiles_np <= 32 && p.nsplit >= 16 && Mrows >= 32768);
     if (dtype == VG_F32)
         vg_launch_timed(1, wgrad_kernel<VG_F32>, grid, dim3(256), 0, s, *d, p.rows_per_split, p.KQ, p.NPpad, xcd_order);
+    else if (wg_use_dma(d) && wg_spec())
+        vg_launch_timed(1, wgrad_bf16_ws_kernel, grid, dim3(WS_NT), 0, s, *d, p.rows_per_split, p.KQ, p.NPpad, xcd_order);
     else if (wg_use_dma(d))
         vg_launch_timed(1, wgrad_bf16_dma_kernel, grid, dim3(256), 0, s, *d, p.rows_per_split, p.KQ, p.NPpad, xcd_order);
     else
