@@ -766,7 +766,8 @@ inline SplitK plan_splitk(const vg_gg_desc* d, int dtype, TileCfg t) {
     const int nstages = ((d->Kp * esz) / 64 + kch - 1) / kch;
     const int gx = (M + t.bm - 1) / t.bm, gy = (d->N + t.bn - 1) / t.bn;
     const int tiles = gx * gy;
-    if (tiles > 32 || nstages < 16) return r;
+    const int max_tiles = [] { const char* e = getenv("VG_SPLITK_MAX_TILES"); return e ? atoi(e) : 32; }();
+    if (tiles > max_tiles || nstages < 16) return r;
     int ks = 256 / tiles;
     if (ks > nstages / 4) ks = nstages / 4;
     if (ks < 2) return r;
