@@ -495,37 +495,45 @@ __global__ __launch_bounds__(256) void wgrad_bf16_dma_kernel(const vg_wg_desc d,
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Wave-specialised form of the LDS-DMA kernel (VG_WG_SPEC=1): the same 128 x 128 tile, LDS image, fragment reads and
-// slab epilogue, but the DMA is issued by EIGHT producer waves while FOUR consumer waves do nothing but transposed
-// fragment reads and MFMA.  Why: in the kernel above a wave issues its 8 global_load_lds of a stage in one burst
-// (60-185 cycles each, MI355X_MICROARCH.md) and only then its 32 MFMAs (512 cycles): the two phases add (ablations in
-// loads alone 28 us, arithmetic alone 30 us, together 55 us) and overlap only through the second
-// workgroup of the CU.  Here issue and arithmetic belong to different waves of ONE workgroup per CU (12 waves = 3 per
-// SIMD), a ring of three 32 KB stages keeps two stages in flight across the single s_barrier per stage, and a producer
-// wave issues 4 DMA instructions per stage (P and Q of row groups pw and pw + 8: (row & 7), the swizzle key, is the
-// same for both, so a lane still fetches one fixed source unit for the whole kernel).
-// MEASURED (S=64 B=128, tools/ab_wgrad_spec.sh; results identical to the kernel above, all wgrad tests pass under
-// VG_WG_SPEC=1): 3-8 % SLOWER -- G2 59.4 vs 55.1 us, G4 57.1 vs 55.0, D1 (2B) 33.3 vs 31.0.  With the DMA issue gone
-// from their instruction stream the four consumer waves (one per SIMD) still need ~1000 cycles per 64-row stage for
-// 512 cycles of MFMA: 16 transposed fragment reads, their latency, 16 MFMAs, twice per stage, and nothing on the SIMD to
-// fill the wait.  That is the same 50 % the two-workgroup kernel reaches with the loads switched off (30 us), so the
-// arithmetic side, not the overlap of issue and arithmetic, is what bounds both.  Kept opt-in as the starting point
-// for a consumer loop with fragment reads pipelined ACROSS the stage barrier.
-constexpr int WS_NBUF = 3, WS_NCONS = 4, WS_NPROD = 8, WS_NT = 64 * (WS_NCONS + WS_NPROD);
+// Wave-specialised form of the LDS-DMA kernel (the default for bf16 where the kq tile count is even; VG_WG_SPEC):
+// the same LDS image, fragment reads and slab epilogue, but DMA issue and arithmetic belong to DIFFERENT waves of one
+// workgroup per CU -- 8 consumer waves (two per SIMD: transposed fragment reads + MFMA only) on a 128 x 256 tile (one
+// P tile, two adjacent Q tiles: 25 % fewer operand bytes per FLOP) and 8 producer waves (row tables, source offsets,
+// global_load_lds only), a ring of three 48 KB stages with two stages in flight across the single s_barrier per
+// stage, counted vmcnt in the producers.  A producer wave owns row groups pw and pw + 8 of every operand tile:
+// (row & 7), the swizzle key, is the same for both, so a lane still fetches one fixed source unit all kernel long.
+// Why it wins where its parts lose (S=64 B=128, tools/ab_wgrad_spec.sh, all wgrad tests pass in every mode):
+//   * one role per wave, 2 workgroups per CU (kernel above):            G1-G4 57 / 55 / 54 / 54 us, step 2.845 ms
+//   * 128 x 256 tile, one role per wave, 1 workgroup per CU:            3-10 % slower (all waves in the same phase)
+//   * 128 x 128 tile, 4 consumers + 8 producers (VG_WG_SPEC=1):         61 / 56 / 56 / 55 us (one consumer per SIMD
+//     needs ~1000 cycles per stage for 512 cycles of MFMA: nothing fills its fragment-read latency)
+//   * 128 x 256 tile, 8 consumers + 4 producers (VG_WG_SPEC=2):         56 / 53 / 51 / 50 us, step 2.797 ms
+//   * 128 x 256 tile, 8 consumers + 8 producers (VG_WG_SPEC=3, default): 47 / 47 / 47 / 45 us = 726-770 TFLOP/s,
+//     step 2.759 ms; wgrad family 458 -> 530 TFLOP/s.
+// The kernels are bound by the per-CU operand ingest (~32 B/clk): the wide tile needs fewer
+// bytes, two consumers per SIMD hide each other's LDS latency, and eight issuing waves keep the DMA stream dense.
+constexpr int WS_NBUF = 3;
 
-__global__ __launch_bounds__(WS_NT) void wgrad_bf16_ws_kernel(const vg_wg_desc d, int rows_per_split, int KQ, int NPpad, int xcd_order) {
-    constexpr int STAGE = 2 * WD_SM * WB_PITCH;
-    static_assert(WD_SM == 64, "producer wave pw owns row groups pw and pw + 8 of a 64-row stage");
+// NQT = 1: 128 x 128 tile, 4 consumer + 8 producer waves.  NQT = 2 (VG_WG_SPEC=2): 128 x 256 tile -- one P tile, two
+// adjacent Q tiles, 8 consumer waves (two per SIMD) + 4 producer waves, 25 % fewer operand bytes per FLOP.
+template <int NQT, int NPROD>
+__global__ __launch_bounds__(64 * (4 * NQT + NPROD)) void wgrad_bf16_ws_kernel(const vg_wg_desc d, int rows_per_split, int KQ, int NPpad, int xcd_order) {
+    constexpr int NCONS = 4 * NQT;
+    constexpr int STAGE = (1 + NQT) * WD_SM * WB_PITCH;      // P | Q0 [| Q1]
+    constexpr int NRG = 16 / NPROD;                           // row groups (of 4 rows) per producer wave and operand tile
+    constexpr int LDMA = NRG * (1 + NQT);                     // DMA instructions per producer wave and stage
+    static_assert(WD_SM == 64 && (NPROD == 8 || NPROD == 4), "producer wave pw owns row groups pw + NPROD * jj of a 64-row stage");
     __shared__ __attribute__((aligned(16))) unsigned char smem[WS_NBUF * STAGE + 4 * WD_SM * 3 * 4];
     int* const rowtab = reinterpret_cast<int*>(smem + WS_NBUF * STAGE);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const bool producer = wave_u >= WS_NCONS;
-    const int pw = wave_u - WS_NCONS;                         // producer index 0..7 (negative for consumers)
-    const int wnp = (wave & 3) >> 1, wkq = wave & 1;          // consumers: 64 x 64 quadrant of the tile
+    const bool producer = wave_u >= NCONS;
+    const int pw = wave_u - NCONS;                            // producer index (negative for consumers)
+    const int wq = NQT == 2 ? (wave >> 2) & 1 : 0;            // consumers: which Q tile
+    const int wnp = (wave & 3) >> 1, wkq = wave & 1;          // consumers: 64 x 64 quadrant of their 128 x 128 tile
     const WgTile bt = wg_tile(xcd_order);
-    const int kq0 = bt.x * WB_T;
+    const int kq00 = bt.x * NQT * WB_T;
     const int np0 = bt.y * WB_T;
     const int M = d.B * d.GH * d.GW;
     const int GHW = d.GH * d.GW;
@@ -536,20 +544,26 @@ __global__ __launch_bounds__(WS_NT) void wgrad_bf16_ws_kernel(const vg_wg_desc d
     if (producer) {
         const int rsub = lane >> 4;                          // row within the 4-row group of one DMA instruction
         const int upos = lane & 15;                          // 16-byte position within the 256-byte LDS row
-        const int key = (4 * pw + rsub) & 7;                 // row & 7 for both row groups of this wave
+        const int key = (4 * pw + rsub) & 7;                 // row & 7 for every row group of this wave (NPROD * 4 % 8 == 0)
         const int unit = (((upos >> 1) ^ key) << 1) | (upos & 1);
-        const int kq_e = kq0 + unit * 8;
-        const bool q_ok = kq_e < KQ;
-        const int t = q_ok ? kq_e / d.QC : 0;
-        const int cq = kq_e - t * d.QC;
-        const int ta = t / d.TW, tb = t - ta * d.TW;
-        const int qdy = d.DY * ta, qdx = d.DX * tb;
+        bool q_ok[NQT];
+        int cq[NQT], qdy[NQT], qdx[NQT];
+#pragma unroll
+        for (int h = 0; h < NQT; ++h) {
+            const int kq_e = kq00 + h * WB_T + unit * 8;
+            q_ok[h] = kq_e < KQ;
+            const int t = q_ok[h] ? kq_e / d.QC : 0;
+            cq[h] = kq_e - t * d.QC;
+            const int ta = t / d.TW, tb = t - ta * d.TW;
+            qdy[h] = d.DY * ta;
+            qdx[h] = d.DX * tb;
+        }
         const bool p_ok = np0 + unit * 8 < d.PC;
         const unsigned char* Pb = reinterpret_cast<const unsigned char*>(d.P);
         const unsigned char* Qb = reinterpret_cast<const unsigned char*>(d.Q);
         const int64_t zoffP = reinterpret_cast<const unsigned char*>(d.zeros) - Pb;
         const int64_t zoffQ = reinterpret_cast<const unsigned char*>(d.zeros) - Qb;
-        const int ptid = tid - 64 * WS_NCONS;                // 0..511
+        const int ptid = tid - 64 * NCONS;
 
         auto fill_table = [&](int slot, int ms) {            // first producer wave: one row per lane
             if (ptid < WD_SM) {
@@ -570,39 +584,52 @@ __global__ __launch_bounds__(WS_NT) void wgrad_bf16_ws_kernel(const vg_wg_desc d
         };
         auto issue_stage = [&](int buf, int slot, int ms) {
             unsigned char* sp = smem + buf * STAGE;
-            unsigned char* sq = sp + WD_SM * WB_PITCH;
+            int e0[NRG], e1[NRG], e2[NRG];
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                const int rg = pw + 8 * jj;                  // row group (4 rows) of this instruction
-                const int r = 4 * rg + rsub;
-                const int m = ms + r;
+            for (int jj = 0; jj < NRG; ++jj) {
+                const int* e = rowtab + (slot * WD_SM + 4 * (pw + NPROD * jj) + rsub) * 3;
+                e0[jj] = e[0]; e1[jj] = e[1]; e2[jj] = e[2];
+            }
+#pragma unroll
+            for (int jj = 0; jj < NRG; ++jj) {
+                const int rg = pw + NPROD * jj;              // row group (4 rows) of these instructions
+                const int m = ms + 4 * rg + rsub;
                 const int64_t offp = (p_ok && m < m_end) ? ((int64_t)m * d.PC + np0 + unit * 8) * 2 : zoffP;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Pb + offp),
                                                  (__attribute__((address_space(3))) void*)(sp + 4 * rg * WB_PITCH),
                                                  16, 0, 0);
-                const int* e = rowtab + (slot * WD_SM + r) * 3;
-                const int iy = e[1] + qdy, ix = e[2] + qdx;
-                const bool ok = q_ok && (unsigned)iy < (unsigned)d.QH && (unsigned)ix < (unsigned)d.QW;
-                const int64_t offq = ok ? ((int64_t)(e[0] + iy * d.QW + ix) * d.QC + cq) * 2 : zoffQ;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Qb + offq),
-                                                 (__attribute__((address_space(3))) void*)(sq + 4 * rg * WB_PITCH),
-                                                 16, 0, 0);
+#pragma unroll
+                for (int h = 0; h < NQT; ++h) {
+                    const int iy = e1[jj] + qdy[h], ix = e2[jj] + qdx[h];
+                    const bool ok = q_ok[h] && (unsigned)iy < (unsigned)d.QH && (unsigned)ix < (unsigned)d.QW;
+                    const int64_t offq = ok ? ((int64_t)(e0[jj] + iy * d.QW + ix) * d.QC + cq[h]) * 2 : zoffQ;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Qb + offq),
+                                                     (__attribute__((address_space(3))) void*)(sp + ((1 + h) * WD_SM + 4 * rg) * WB_PITCH),
+                                                     16, 0, 0);
+                }
             }
         };
         // row tables of the first three stages, visible to all producer waves before the first issue
 #pragma unroll
         for (int p = 0; p < WS_NBUF; ++p)
             if (p < nstage) fill_table(p, m_begin + p * WD_SM);
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                   // barrier P (all 12 waves)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                   // barrier P (all waves)
         if (nstage > 0) issue_stage(0, 0, m_begin);
         if (nstage > 1) issue_stage(1, 1, m_begin + WD_SM);
         for (int s = 0; s < nstage; ++s) {
-            // stage s has landed once at most the 4 instructions of stage s+1 are outstanding (in-order completion)
-            if (s + 1 < nstage) WG_WAITCNT_VM(4); else WG_WAITCNT_VM(0);
+            // stage s has landed once at most the LDMA instructions of stage s+1 are outstanding (in-order completion)
+            if (s + 1 < nstage) {
+                if constexpr (LDMA == 4) WG_WAITCNT_VM(4);
+                else if constexpr (LDMA == 6) WG_WAITCNT_VM(6);
+                else WG_WAITCNT_VM(12);
+            } else {
+                WG_WAITCNT_VM(0);
+            }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");               // barrier s: consumers may read s,
             if (s + 2 < nstage) issue_stage((s + 2) % WS_NBUF, (s + 2) & 3, m_begin + (s + 2) * WD_SM);   // slot of s-1 is free
             if (s + 3 < nstage) fill_table((s + 3) & 3, m_begin + (s + 3) * WD_SM);
         }
+        static_assert(LDMA == 4 || LDMA == 6 || LDMA == 12, "vmcnt literals above");
         return;
     }
 
@@ -616,7 +643,7 @@ __global__ __launch_bounds__(WS_NT) void wgrad_bf16_ws_kernel(const vg_wg_desc d
     for (int s = 0; s < nstage; ++s) {
         __builtin_amdgcn_s_barrier();                                                      // barrier s
         const unsigned char* sp = smem + (s % WS_NBUF) * STAGE;
-        const unsigned char* sq = sp + WD_SM * WB_PITCH;
+        const unsigned char* sq = sp + (1 + wq) * WD_SM * WB_PITCH;
 #pragma unroll
         for (int ks = 0; ks < WD_SM / 32; ++ks) {
             bf16x8 a[4], b[4];
@@ -631,8 +658,9 @@ __global__ __launch_bounds__(WS_NT) void wgrad_bf16_ws_kernel(const vg_wg_desc d
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
     }
-    const int ldk = gridDim.x * WB_T;
+    const int ldk = gridDim.x * NQT * WB_T;
     float* slab = d.ws + (int64_t)bt.z * NPpad * (int64_t)ldk;
+    const int kq0 = kq00 + wq * WB_T;
     const int fi = lane & 15, fk = lane >> 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -814,9 +842,11 @@ inline int wg_target() {
     return v;
 }
 
-inline bool wg_spec() {                     // per call: tests and A/B scripts flip it
+// 0: one role per wave (wgrad_bf16_dma_kernel); 1: 128 x 128 tile, 4 consumer + 8 producer waves; 2: 128 x 256 tile,
+// 8 consumers + 4 producers; 3 (default): 128 x 256 tile, 8 consumers + 8 producers.  Read per call (tests, A/B scripts).
+inline int wg_spec() {
     const char* e = getenv("VG_WG_SPEC");
-    return e ? atoi(e) != 0 : false;
+    return e ? atoi(e) : 3;
 }
 
 inline bool wg_use_dma(const vg_wg_desc* d) {
@@ -886,8 +916,14 @@ extern "C" int vg_wgrad(const vg_wg_desc* d, int dtype, void* stream) {
     const int xcd_order = xcd_env == 2 || (xcd_env == 1 && p.tiles_kq * p.tiles_np <= 32 && p.nsplit >= 16 && Mrows >= 32768);
     if (dtype == VG_F32)
         vg_launch_timed(1, wgrad_kernel<VG_F32>, grid, dim3(256), 0, s, *d, p.rows_per_split, p.KQ, p.NPpad, xcd_order);
-    else if (wg_use_dma(d) && wg_spec())
-        vg_launch_timed(1, wgrad_bf16_ws_kernel, grid, dim3(WS_NT), 0, s, *d, p.rows_per_split, p.KQ, p.NPpad, xcd_order);
+    else if (wg_use_dma(d) && wg_spec() == 3 && p.tiles_kq % 2 == 0)
+        vg_launch_timed(1, (wgrad_bf16_ws_kernel<2, 8>), dim3(p.tiles_kq / 2, p.tiles_np, p.nsplit), dim3(1024), 0, s, *d,
+                        p.rows_per_split, p.KQ, p.NPpad, xcd_order);
+    else if (wg_use_dma(d) && wg_spec() == 2 && p.tiles_kq % 2 == 0)
+        vg_launch_timed(1, (wgrad_bf16_ws_kernel<2, 4>), dim3(p.tiles_kq / 2, p.tiles_np, p.nsplit), dim3(768), 0, s, *d,
+                        p.rows_per_split, p.KQ, p.NPpad, xcd_order);
+    else if (wg_use_dma(d) && wg_spec() != 0)
+        vg_launch_timed(1, (wgrad_bf16_ws_kernel<1, 8>), grid, dim3(768), 0, s, *d, p.rows_per_split, p.KQ, p.NPpad, xcd_order);
     else if (wg_use_dma(d))
         vg_launch_timed(1, wgrad_bf16_dma_kernel, grid, dim3(256), 0, s, *d, p.rows_per_split, p.KQ, p.NPpad, xcd_order);
     else
