@@ -508,6 +508,7 @@ PATCH_CASES = [  # kind, B, H (input), Cin, Cout      (k4 s2 p1 everywhere; all 
     ("convT", 8, 16, 128, 64), ("conv", 8, 32, 64, 64), ("conv_dgrad", 8, 32, 64, 128), ("convT", 2, 32, 96, 40),  # 128 x 64 tile
     ("convT", 16, 4, 256, 128), ("conv", 16, 8, 128, 256), ("convT_dgrad", 16, 4, 128, 256),   # 4 x 4 grids: 8 images per tile
     ("convT", 2, 64, 32, 128), ("conv", 2, 128, 32, 128),                                     # 64-wide grids
+    ("convT", 4, 32, 64, 32), ("conv_dgrad", 4, 64, 32, 64), ("conv", 4, 64, 32, 32), ("convT", 2, 64, 64, 32),   # 128 x 32 tile (S >= 128 layers)
 ]
 
 

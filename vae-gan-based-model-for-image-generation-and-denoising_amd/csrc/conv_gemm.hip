@@ -701,6 +701,11 @@ inline bool patch64() {                     // patch variant for the 128 x 64 ti
     return e ? atoi(e) != 0 : true;
 }
 
+inline bool patch32() {                     // patch variant for 32-output-channel layers (S >= 128: VG_GG_PATCH32=0 turns it off)
+    const char* e = getenv("VG_GG_PATCH32");
+    return e ? atoi(e) != 0 : true;
+}
+
 inline int patch256_min() {
     const char* e = getenv("VG_PATCH256_MIN");
     return e ? atoi(e) : 256;               // 256 x 128 tiles where every CU gets at least one (step sweep: 128 / 192 / 256 / 384 -> 38.3 / 38.6 / 38.7 / 38.7k img/s)
@@ -886,7 +891,7 @@ extern "C" int vg_gather_gemm(const vg_gg_desc* d, int dtype, void* stream) {
     if (dtype == VG_F32) return dispatch<VG_F32>(d, t, vg_stream(stream), sk);
     if (dtype == VG_FP8) return dispatch<VG_FP8>(d, t, vg_stream(stream), sk);
     if (narrowk_ok(d, dtype)) return launch_narrowk(d, vg_stream(stream));
-    if ((t.bm == 128 || t.bm == 256) && (t.bn == GP_BN || (t.bn == 64 && patch64())) && sk.ksplit <= 1 &&
+    if ((t.bm == 128 || t.bm == 256) && (t.bn == GP_BN || (t.bn == 64 && patch64()) || (t.bn == 32 && d->N == 32 && patch32())) && sk.ksplit <= 1 &&
         use_patch() && use_dma() && d->zeros != nullptr && patch_geometry(d, t.bm, &pg)) {
         const int m_tiles = (d->B * d->GH * d->GW) / t.bm, n_tiles = (d->N + t.bn - 1) / t.bn;
         dim3 grid(((m_tiles + 7) / 8) * 8 * n_tiles, 1, d->nphase);
@@ -894,6 +899,7 @@ extern "C" int vg_gather_gemm(const vg_gg_desc* d, int dtype, void* stream) {
         if (t.bm == 256 && t.bn == 64) vg_launch_timed(0, (ggp_kernel<4, 64>), grid, dim3(512), 0, vg_stream(stream), *d, pg);
         else if (t.bm == 256) vg_launch_timed(0, ggp_kernel<4>, grid, dim3(512), 0, vg_stream(stream), *d, pg);
         else if (t.bn == 64) vg_launch_timed(0, (ggp_kernel<2, 64>), grid, dim3(256), 0, vg_stream(stream), *d, pg);
+        else if (t.bn == 32) vg_launch_timed(0, (ggp_kernel<2, 32>), grid, dim3(256), 0, vg_stream(stream), *d, pg);
         else vg_launch_timed(0, ggp_kernel<2>, grid, dim3(256), 0, vg_stream(stream), *d, pg);
         return VG_LAUNCH_RC();
     }

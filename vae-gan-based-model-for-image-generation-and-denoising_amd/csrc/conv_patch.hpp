@@ -48,7 +48,7 @@ __device__ __forceinline__ void gp_wait(int n) {
 //         tiles (G3 fprop 742 -> 780, G4 dgrad 689 -> 750 TFLOP/s) and loses at 256 tiles (G2 fprop 835 -> 806).
 template <int WM, int BN = GP_BN>
 __global__ __launch_bounds__(128 * WM, WM == 4 ? 2 : 1) void ggp_kernel(const vg_gg_desc d, const PatchGeo g) {
-    // BN = 128: wave tile 64 x 64; BN = 64 (layers with <= 64 output channels): wave tile 64 x 32
+    // BN = 128: wave tile 64 x 64; BN = 64 (layers with <= 64 output channels): wave tile 64 x 32; BN = 32: 64 x 16
     constexpr int BM = 64 * WM, WN = 2, TM = 4, TN = BN / 32, NT = 128 * WM, BST = BN * 64, WNC = BN / 2;
     constexpr int NR = (WM == 4 || GP_TPS != 2) ? 3 : 4;   /* WM == 4: 3 rounds of 512 lanes = 384 pixels */   // patch DMA rounds: 192 (3) or 256 (4) pixels per 128 rows
     constexpr int GP_PBUF = NR * NT * 16;           // NR rounds of NT lanes x 16 B
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 2 : 1) void ggp_kernel(const vg
     // 256 x 64: the 64-row weight tile needs only 256 of the 512 lanes -> waves 4-7 skip the weight DMA (legal here:
     // that variant never uses counted vmcnt waits, every stage drains with vmcnt(0))
     constexpr bool B_HALF = (BN * 4 < NT);
-    static_assert(BN == 128 || BN == 64, "supported shapes");
+    static_assert(BN == 128 || BN == 64 || BN == 32, "supported shapes");
     static_assert(!B_HALF || TPS >= 2, "partial weight issue needs the drain-every-stage loop");
     // [patch buffers 2 x 12|24 KB][weight ring 3 x 8 KB][output-pixel table]
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * GP_PBUF + NB * BSTAGE + BM * 4];
@@ -246,6 +246,9 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 2 : 1) void ggp_kernel(const vg
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 10, 0);
 #endif
+        } else if constexpr (TN == 1) {
+            ld_a(0); ld_b(0); ld_a(1); ld_a(2); ld_a(3);
+            GP_MFMA(0, 0); GP_MFMA(1, 0); GP_MFMA(2, 0); GP_MFMA(3, 0);
         } else {
             ld_a(0); ld_b(0); ld_b(1); ld_a(1); ld_a(2); ld_a(3);
             GP_MFMA(0, 0); GP_MFMA(0, 1);
