@@ -48,7 +48,8 @@ extern "C" {
 #define VG_ACT_LRELU   2   /* nn.LeakyReLU(slope)    main_vae.py:25, gan_code.py:62-82 */
 #define VG_ACT_TANH    3   /* nn.Tanh()              gan_code.py:50 (vg_tnconv epilogue only) */
 
-#define VG_ABI_VERSION 3   /* 2: vg_pack_desc.tile_start, SyncBN / WGAN / data-path entry points; 3: in-kernel noise (vg_*_rng) */
+#define VG_ABI_VERSION 4   /* 2: vg_pack_desc.tile_start, SyncBN / WGAN / data-path entry points; 3: in-kernel noise (vg_*_rng);
+                             4: vg_bn_finalize_act_forward */
 int vg_abi_version(void);
 /* Live kernel timing for the roofline report: while enabled, gather-GEMM (family 0) and wgrad (family 1)
  * launches carry a HIP start/stop event pair on their stream (hipExtLaunchKernelGGL); collect() synchronises,
@@ -182,6 +183,17 @@ int vg_bn_finalize(const float* stats, int nparts, int C, int64_t count,
 int vg_bn_finalize_grouped(const float* stats, int nparts_per_group, int groups, int C, int64_t count_per_group,
                            const float* gamma, const float* beta, float* running_mean, float* running_var,
                            float momentum, float eps, float* coeffs, void* stream);
+/* vg_bn_finalize_grouped + vg_bn_act_forward in ONE launch, for small layers (bf16, <= 200 slab rows per group, tensor <= 9 MB,
+ * C % 64 == 0): every workgroup of the elementwise pass re-derives the coefficients of its 64
+ * channels from the slab (same double-precision sums, another order: coefficients may differ from vg_bn_finalize_grouped
+ * in the last bit).  Writes coeffs [groups][4][C] and the running statistics like vg_bn_finalize_grouped.
+ * vg_bn_finalize_act_forward_supported() says whether a shape qualifies (VG_BN_FUSED_FWD=0 turns the path off); the
+ * launch returns VG_ENOSUP otherwise.  rows = all groups' rows; x, y: [rows][C] bf16. */
+int vg_bn_finalize_act_forward_supported(int nparts_per_group, int groups, int C, int64_t rows, int dtype);
+int vg_bn_finalize_act_forward(const void* x, void* y, const float* stats, int nparts_per_group, int groups, int C,
+                               int64_t rows, const float* gamma, const float* beta, float* running_mean,
+                               float* running_var, float momentum, float eps, float* coeffs, int act, float slope,
+                               int dtype, void* stream);
 int vg_bn_backward_finalize_grouped(const float* partial, int nparts_per_group, int groups, int C,
                                     int64_t count_per_group, const float* gamma, const float* coeffs,
                                     float* dgamma, float* dbeta, int accumulate, float* coef, void* stream);

@@ -647,3 +647,45 @@ def test_workgroup_order_switches_do_not_change_results(ops, monkeypatch, kind, 
         res[mode] = (Y.clone(), DX.clone(), dW)
     for a_, b_ in zip(res["0"], res["2"]):
         assert torch.equal(a_, b_)
+
+
+@pytest.mark.parametrize("rpg,C,groups,act,slope", [(2048, 512, 2, 2, 0.2), (4096, 256, 1, 1, 0.0), (512, 1024, 1, 1, 0.0), (4608, 128, 1, 2, 0.01)])
+def test_bn_finalize_and_forward_in_one_launch(ops, monkeypatch, rpg, C, groups, act, slope):
+    """bf16 train-mode BatchNorm with a small statistics slab: vg_bn_finalize_act_forward (every workgroup re-derives its
+    64 channels' coefficients) against vg_bn_finalize_grouped + vg_bn_act_forward -- coefficients, running statistics
+    (updated group after group) and the activated output."""
+    dt = G.BF16
+    rows = rpg * groups
+    g = torch.Generator().manual_seed(rpg + C)
+    x = (torch.randn(rows, C, generator=g) * 1.5 + 0.4).to(DEV).to(torch.bfloat16)
+    gamma = (torch.randn(C, generator=g) * 0.1 + 1).to(DEV)
+    beta = (torch.randn(C, generator=g) * 0.1).to(DEV)
+    stats, nparts = [], 0
+    for k in range(groups):                                   # one slab block per group, as the grouped forward emits them
+        st, n = ops.channel_stats(x[k * rpg:(k + 1) * rpg], rpg, C, dt)
+        stats.append(st[: n * 2 * C].clone())
+        nparts += n
+    stats = torch.cat(stats)
+    assert nparts // groups <= 200
+    rm1, rv1 = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    co1 = ops.bn_finalize(stats, nparts, C, rows, gamma, beta, rm1, rv1, 0.1, 1e-5, DEV, groups=groups)
+    y1 = ops.bn_act_forward(x, co1, rows, C, act, slope, dt)
+    rm2, rv2 = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    res = ops.bn_finalize_act_forward(x, stats, nparts, C, rows, gamma, beta, rm2, rv2, 0.1, 1e-5, act, slope, dt, groups=groups)
+    assert res is not None
+    co2, y2 = res
+    torch.cuda.synchronize()
+    torch.testing.assert_close(co2, co1, rtol=2e-6, atol=1e-6)
+    torch.testing.assert_close(rm2, rm1, rtol=2e-6, atol=1e-7)
+    torch.testing.assert_close(rv2, rv1, rtol=2e-6, atol=1e-7)
+    d = (y2.float() - y1.float()).abs()
+    assert float(d.max()) <= 2.0 ** -7 * float(y1.float().abs().max()) and float((d > 0).float().mean()) < 1e-3
+    # reference semantics: torch batch_norm in fp64 on the same bf16 input, per group
+    for k in range(groups):
+        xs = x[k * rpg:(k + 1) * rpg].double().cpu().view(rpg, C, 1, 1)
+        z = F.batch_norm(xs, None, None, gamma.double().cpu(), beta.double().cpu(), True, 0.1, 1e-5)
+        ref = (F.leaky_relu(z, slope) if act == 2 else F.relu(z)).view(rpg, C)
+        torch.testing.assert_close(y2[k * rpg:(k + 1) * rpg].double().cpu(), ref, **TOL[dt])
+    monkeypatch.setenv("VG_BN_FUSED_FWD", "0")
+    assert ops.bn_finalize_act_forward(x, stats, nparts, C, rows, gamma, beta, rm2, rv2, 0.1, 1e-5, act, slope, dt, groups=groups) is None
+    assert ops.bn_finalize_act_forward(x.float(), stats, nparts, C, rows, gamma, beta, rm2, rv2, 0.1, 1e-5, act, slope, G.F32, groups=groups) is None

@@ -16,7 +16,7 @@ VG_F32, VG_BF16, VG_FP8 = 0, 1, 2
 VG_FP8_WSHIFT = 6
 VG_ACT_NONE, VG_ACT_RELU, VG_ACT_LRELU, VG_ACT_TANH = 0, 1, 2, 3
 VG_MAX_PHASE = 4
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _ERR = {-1: "VG_EINVAL (bad shape/size/flag)", -2: "VG_EALIGN (16-byte contract violated)",
         -3: "VG_ENOSUP (unsupported configuration)"}
@@ -107,6 +107,8 @@ SIGNATURES = {
     "vg_bn_act_backward_reduce": (c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _P, _I, POINTER(c_int), _I, _L,
                                           _I, _P]),
     "vg_bn_backward_finalize": (c_int, [_P, _I, _I, _L, _P, _P, _P, _P, _I, _P, _P]),
+    "vg_bn_finalize_act_forward_supported": (c_int, [_I, _I, _I, _L, _I]),
+    "vg_bn_finalize_act_forward": (c_int, [_P, _P, _P, _I, _I, _I, _L, _P, _P, _P, _P, _F, _F, _P, _I, _F, _I, _P]),
     "vg_bn_act_backward_apply": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _I, _L, _L, _I, _P]),
     "vg_act_backward": (c_int, [_P, _P, _P, _L, _I, _F, _I, _P]),
     "vg_bias_grad": (c_int, [_P, _L, _I, _I, _P, _I, _P, _I, _I, _P]),

@@ -395,6 +395,113 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const void* __res
     for (; i < nvec; i += stride) one(i, load4<DT>(x, i * 4), load4<DT>(dy, i * 4));
 }
 
+// ---- train-mode BatchNorm finalize + normalise + activation in ONE launch (bf16, small statistics slabs) ----------
+// bn_finalize_grouped_kernel is a 5 us launch whose only output is 4 C floats; for layers whose slab is small
+// (<= 200 rows per group, tensor <= 9 MB) every workgroup of the elementwise pass can afford to redo it: a workgroup of 1024 threads
+// owns 64 channels of a block of rows, sums the slab rows of its group for those channels (16 part lanes x 64
+// channels, double, fixed order -- every workgroup of a channel slice computes bit-identical coefficients), keeps
+// scale / shift in LDS and applies them.  The workgroups of row block 0 also publish the coefficients
+// ([groups][4][C], what the backward pass reads) and update the running statistics, group after group.
+constexpr int FF_CH = 64, FF_PL = 16, FF_TH = FF_CH * FF_PL, FF_MAXPARTS = 200;
+constexpr int64_t FF_MAXBYTES = 9ll << 20;       // tensor size up to which re-deriving the coefficients per workgroup pays
+
+__device__ __forceinline__ void ff_slice_stats(const float* __restrict__ slabs, int nparts, int C, int c0, double count,
+                                               double (*red)[FF_CH][2], double& mu_out, double& var_out) {
+    const int ch = threadIdx.x & (FF_CH - 1), pl = threadIdx.x / FF_CH;
+    double a = 0.0, b = 0.0;
+    for (int p = pl; p < nparts; p += FF_PL) {
+        a += (double)slabs[((int64_t)p * 2 + 0) * C + c0 + ch];
+        b += (double)slabs[((int64_t)p * 2 + 1) * C + c0 + ch];
+    }
+    red[pl][ch][0] = a;
+    red[pl][ch][1] = b;
+    __syncthreads();
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < FF_PL; ++k) { s1 += red[k][ch][0]; s2 += red[k][ch][1]; }
+    const double mu = s1 / count;
+    double var = s2 / count - mu * mu;
+    if (var < 0.0) var = 0.0;
+    mu_out = mu;
+    var_out = var;
+    __syncthreads();                                           // red[] is reused by the next group (publisher blocks)
+}
+
+__global__ __launch_bounds__(FF_TH) void bn_fin_act_fwd_kernel(
+    const uint16_t* __restrict__ x, uint16_t* __restrict__ y, const float* __restrict__ stats, int nparts, int groups,
+    int C, double count, const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ rmean,
+    float* __restrict__ rvar, float momentum, float eps, float* __restrict__ coeffs, int64_t rows_per_group,
+    int rows_per_block, int act, float slope) {
+    __shared__ double red[FF_PL][FF_CH][2];
+    __shared__ float s_sc[FF_CH], s_sh[FF_CH];
+    const int tid = threadIdx.x, ch = tid & (FF_CH - 1);
+    const int c0 = blockIdx.y * FF_CH, grp = blockIdx.z;
+    const bool lead = tid < FF_CH && c0 + ch < C;              // one thread per channel of the slice
+    const float gm = (lead && gamma) ? gamma[c0 + ch] : 1.f, bt = (lead && beta) ? beta[c0 + ch] : 0.f;
+    if (blockIdx.x == 0 && grp == 0) {
+        // publisher of this channel slice: every group's coefficients, running statistics in group order
+        float rm = (lead && rmean) ? rmean[c0 + ch] : 0.f, rv = (lead && rmean) ? rvar[c0 + ch] : 0.f;
+        for (int g = 0; g < groups; ++g) {
+            double mu, var;
+            ff_slice_stats(stats + (int64_t)g * nparts * 2 * C, nparts, C, c0, count, red, mu, var);
+            if (lead) {
+                const float is = (float)(1.0 / sqrt(var + (double)eps));
+                const float muf = (float)mu, sc = gm * is, sh = bt - muf * sc;
+                float* co = coeffs + (int64_t)g * 4 * C + c0 + ch;
+                co[0] = muf; co[C] = is; co[2 * C] = sc; co[3 * C] = sh;
+                if (g == 0) { s_sc[ch] = sc; s_sh[ch] = sh; }
+                if (rmean) {
+                    const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
+                    rm = (1.f - momentum) * rm + momentum * muf;
+                    rv = (1.f - momentum) * rv + momentum * (float)unbiased;
+                }
+            }
+        }
+        if (lead && rmean) { rmean[c0 + ch] = rm; rvar[c0 + ch] = rv; }
+    } else {
+        double mu, var;
+        ff_slice_stats(stats + (int64_t)grp * nparts * 2 * C, nparts, C, c0, count, red, mu, var);
+        if (lead) {
+            const float is = (float)(1.0 / sqrt(var + (double)eps));
+            const float muf = (float)mu, sc = gm * is;
+            s_sc[ch] = sc;
+            s_sh[ch] = bt - muf * sc;
+        }
+    }
+    __syncthreads();
+    // ---- apply: a thread owns 8 channels (16 bytes) of a row; 8 threads per row, 128 rows per pass ----
+    const int u8 = (tid & 7) * 8, rl = tid >> 3;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sc[k] = s_sc[u8 + k]; sh[k] = s_sh[u8 + k]; }
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < rows_per_group ? r0 + rows_per_block : rows_per_group;
+    const int64_t base = (int64_t)grp * rows_per_group;
+    if (c0 + u8 < C) {
+        for (int64_t r = r0 + rl; r < r1; r += FF_TH / 8) {
+            const int64_t off = (base + r) * C + c0 + u8;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(x + off);
+            u32x4 o;
+#pragma unroll
+            for (int k2 = 0; k2 < 4; ++k2) {
+                const float lo = act_fwd(sc[2 * k2] * __uint_as_float(v[k2] << 16) + sh[2 * k2], act, slope);
+                const float hi = act_fwd(sc[2 * k2 + 1] * __uint_as_float(v[k2] & 0xffff0000u) + sh[2 * k2 + 1], act, slope);
+                o[k2] = (uint32_t)ElemT<VG_BF16>::from_f32(lo) | ((uint32_t)ElemT<VG_BF16>::from_f32(hi) << 16);
+            }
+            *reinterpret_cast<u32x4*>(y + off) = o;
+        }
+    }
+}
+
+inline bool bn_fin_fwd_ok(int nparts_per_group, int groups, int C, int64_t rows, int dtype) {
+    const char* e = getenv("VG_BN_FUSED_FWD");                  // read per call: tests flip it
+    const int mode = e ? atoi(e) : 1;
+    // measured per shape (tools/bn_fwd_bench.py, S=64 B=128): wins 1-3 us per layer up to 8.4 MB / 196 slab rows
+    // (G0 7.2 -> 4.5, D3 6.2 -> 4.3, E3 5.5 -> 3.8 us), loses beyond (G2 16.8 MB 13.4 -> 15.0, D1 256 slab rows 9.1 -> 11.4)
+    return mode != 0 && dtype == VG_BF16 && C % FF_CH == 0 && groups >= 1 && rows % groups == 0 &&
+           nparts_per_group > 0 && nparts_per_group <= FF_MAXPARTS && rows * C * 2 <= FF_MAXBYTES;
+}
+
 template <int DT>
 __global__ __launch_bounds__(256) void act_bwd_kernel(const void* __restrict__ x, const void* __restrict__ dy,
                                                       void* __restrict__ dx, int64_t nvec, int act, float slope) {
@@ -531,6 +638,33 @@ extern "C" int vg_bn_eval_coeffs(const float* gamma, const float* beta, const fl
     VG_CHECK_ARG(running_mean && running_var && scale && shift && C > 0, VG_EINVAL);
     hipLaunchKernelGGL(bn_eval_kernel, dim3((C + 63) / 64), dim3(64), 0, vg_stream(stream), gamma, beta, running_mean,
                        running_var, eps, C, scale, shift);
+    return VG_LAUNCH_RC();
+}
+
+extern "C" int vg_bn_finalize_act_forward_supported(int nparts_per_group, int groups, int C, int64_t rows, int dtype) {
+    return bn_fin_fwd_ok(nparts_per_group, groups, C, rows, dtype) ? 1 : 0;
+}
+
+extern "C" int vg_bn_finalize_act_forward(const void* x, void* y, const float* stats, int nparts_per_group, int groups,
+                                          int C, int64_t rows, const float* gamma, const float* beta,
+                                          float* running_mean, float* running_var, float momentum, float eps,
+                                          float* coeffs, int act, float slope, int dtype, void* stream) {
+    VG_CHECK_ARG(x && y && stats && coeffs && rows > 0 && C > 0, VG_EINVAL);
+    VG_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), VG_EINVAL);
+    VG_CHECK_ARG(vg_aligned16(x) && vg_aligned16(y), VG_EALIGN);
+    if (!bn_fin_fwd_ok(nparts_per_group, groups, C, rows, dtype)) return VG_ENOSUP;
+    const int64_t rpg = rows / groups;
+    // ~512 workgroups in all; whole passes of 128 rows per workgroup
+    const int slices = C / FF_CH;
+    int64_t want = 512 / (slices * groups);
+    if (want < 1) want = 1;
+    int64_t rpb = (rpg + want - 1) / want;
+    rpb = (rpb + 127) / 128 * 128;
+    const int rb = (int)((rpg + rpb - 1) / rpb);
+    hipLaunchKernelGGL(bn_fin_act_fwd_kernel, dim3(rb, slices, groups), dim3(FF_TH), 0, vg_stream(stream),
+                       reinterpret_cast<const uint16_t*>(x), reinterpret_cast<uint16_t*>(y), stats, nparts_per_group, groups,
+                       C, (double)rpg, gamma, beta, running_mean, running_var, momentum, eps, coeffs, rpg, (int)rpb, act,
+                       slope);
     return VG_LAUNCH_RC();
 }
 

@@ -389,15 +389,25 @@ class StackEngine:
             coeffs = None
             if st.bn is not None:
                 bn = st.bn
-                if train:
+                nxt8 = i + 1 < len(self.stages) and self.stages[i + 1].kind != "head" and self.fp8_ok(i + 1)
+                fused = None
+                if train and self.bn_sync is None and not nxt8 and st.cout == OC:
+                    # small statistics slab: finalize + normalise + activation in one launch
+                    fused = ops.bn_finalize_act_forward(Y, stats, nparts, OC, rows, bn.weight.detach(), bn.bias.detach(),
+                                                        bn.running_mean, bn.running_var, BN_MOMENTUM, BN_EPS, st.act,
+                                                        st.slope, dt, groups=groups)
+                if fused is not None:
+                    coeffs = fused[0]
+                elif train:
                     coeffs = ops.bn_finalize(stats, nparts, st.cout, rows, bn.weight.detach(), bn.bias.detach(),
                                              bn.running_mean, bn.running_var, BN_MOMENTUM, BN_EPS, Y.device,
                                              groups=groups, sync=self.bn_sync)
                 else:
                     coeffs = ops.bn_eval_coeffs(bn.weight.detach(), bn.bias.detach(), bn.running_mean,
                                                 bn.running_var, BN_EPS)
-                nxt8 = i + 1 < len(self.stages) and self.stages[i + 1].kind != "head" and self.fp8_ok(i + 1)
-                if nxt8:                                    # the next layer's fp8 operand comes out of this same pass
+                if fused is not None:
+                    out, out8 = fused[1], None
+                elif nxt8:                                  # the next layer's fp8 operand comes out of this same pass
                     out, out8 = ops.bn_act_forward(Y, coeffs, rows, OC, st.act, st.slope, dt, want_fp8=True)
                 else:
                     out, out8 = ops.bn_act_forward(Y, coeffs, rows, OC, st.act, st.slope, dt), None

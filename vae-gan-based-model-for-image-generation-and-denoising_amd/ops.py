@@ -492,6 +492,24 @@ def bn_act_forward(x, coeffs, rows, C, act, slope, dtype, out=None, want_fp8=Fal
     return y
 
 
+def bn_finalize_act_forward(x, stats, nparts, C, rows, gamma, beta, running_mean, running_var, momentum, eps, act, slope,
+                            dtype, groups=1):
+    """Train-mode finalize + normalise + activation in one launch where the statistics slab is small
+    (bn_act.hip bn_fin_act_fwd_kernel).  Returns (coeffs [groups][4][C], y), or None when the shape does not qualify
+    (the caller then runs bn_finalize + bn_act_forward)."""
+    lib = L.load()
+    if BINDING == "torchops" or x.shape[-1] != C or \
+            not lib.vg_bn_finalize_act_forward_supported(nparts // groups, groups, C, rows, dtype):
+        return None
+    _need_cuda(x, stats)
+    co = torch.empty(groups, 4, C, dtype=torch.float32, device=x.device)
+    y = torch.empty_like(x)
+    L.check(lib.vg_bn_finalize_act_forward(x.data_ptr(), y.data_ptr(), stats.data_ptr(), nparts // groups, groups, C, rows,
+                                           L.ptr(gamma), L.ptr(beta), L.ptr(running_mean), L.ptr(running_var), momentum, eps,
+                                           co.data_ptr(), act, slope, dtype, L.stream_ptr()), "vg_bn_finalize_act_forward")
+    return co, y
+
+
 def channel_stats(x, rows, C, dtype):
     n = c_int(0)
     cap = 1024
