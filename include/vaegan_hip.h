@@ -49,7 +49,7 @@ extern "C" {
 #define VG_ACT_TANH    3   /* nn.Tanh()              gan_code.py:50 (vg_tnconv epilogue only) */
 
 #define VG_ABI_VERSION 4   /* 2: vg_pack_desc.tile_start, SyncBN / WGAN / data-path entry points; 3: in-kernel noise (vg_*_rng);
-                             4: vg_bn_finalize_act_forward */
+                             4: vg_bn_finalize_act_forward, vg_bn_backward_finalize_apply */
 int vg_abi_version(void);
 /* Live kernel timing for the roofline report: while enabled, gather-GEMM (family 0) and wgrad (family 1)
  * launches carry a HIP start/stop event pair on their stream (hipExtLaunchKernelGGL); collect() synchronises,
@@ -194,6 +194,12 @@ int vg_bn_finalize_act_forward(const void* x, void* y, const float* stats, int n
                                int64_t rows, const float* gamma, const float* beta, float* running_mean,
                                float* running_var, float momentum, float eps, float* coeffs, int act, float slope,
                                int dtype, void* stream);
+/* Backward twin: vg_bn_backward_finalize_grouped + vg_bn_act_backward_apply in one launch, same eligibility
+ * (vg_bn_finalize_act_forward_supported with the column-reduce partial count); VG_ENOSUP otherwise. */
+int vg_bn_backward_finalize_apply(const void* x, const void* dy, void* dx, const float* partial, int nparts_per_group,
+                                  int groups, int C, int64_t rows, const float* gamma, const float* coeffs,
+                                  float* dgamma, float* dbeta, int accumulate, int act, float slope, int dtype,
+                                  void* stream);
 int vg_bn_backward_finalize_grouped(const float* partial, int nparts_per_group, int groups, int C,
                                     int64_t count_per_group, const float* gamma, const float* coeffs,
                                     float* dgamma, float* dbeta, int accumulate, float* coef, void* stream);

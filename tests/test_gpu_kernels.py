@@ -689,3 +689,40 @@ def test_bn_finalize_and_forward_in_one_launch(ops, monkeypatch, rpg, C, groups,
     monkeypatch.setenv("VG_BN_FUSED_FWD", "0")
     assert ops.bn_finalize_act_forward(x, stats, nparts, C, rows, gamma, beta, rm2, rv2, 0.1, 1e-5, act, slope, dt, groups=groups) is None
     assert ops.bn_finalize_act_forward(x.float(), stats, nparts, C, rows, gamma, beta, rm2, rv2, 0.1, 1e-5, act, slope, G.F32, groups=groups) is None
+
+
+@pytest.mark.parametrize("rpg,C,groups,act,slope", [(2048, 512, 2, 2, 0.2), (4096, 256, 1, 1, 0.0), (4608, 128, 1, 2, 0.01)])
+def test_bn_backward_finalize_and_apply_in_one_launch(ops, monkeypatch, rpg, C, groups, act, slope):
+    """bf16 BatchNorm backward of a small layer: vg_bn_backward_finalize_apply (through ops.bn_act_backward) against the
+    grouped finalize + apply it replaces (VG_BN_FUSED_FWD=0): dx, and dgamma / dbeta accumulated onto old values in
+    group order."""
+    dt = G.BF16
+    rows = rpg * groups
+    g = torch.Generator().manual_seed(rpg * 3 + C)
+    x = (torch.randn(rows, C, generator=g) * 1.3 + 0.2).to(DEV).to(torch.bfloat16)
+    dy = torch.randn(rows, C, generator=g).to(DEV).to(torch.bfloat16)
+    gamma = (torch.randn(C, generator=g) * 0.1 + 1).to(DEV)
+    beta = (torch.randn(C, generator=g) * 0.1).to(DEV)
+    xs = x.float().view(groups, rpg, C)
+    mean, var = xs.mean(1), xs.var(1, unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    scale = gamma * invstd
+    co = torch.stack([mean, invstd, scale, beta - mean * scale], 1).contiguous()
+    seed_g, seed_b = torch.randn(C, generator=g).to(DEV), torch.randn(C, generator=g).to(DEV)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("VG_BN_FUSED_FWD", mode)
+        dg, db = seed_g.clone(), seed_b.clone()
+        dx = ops.bn_act_backward(x, dy, co, rows, C, rows, gamma, act, slope, dg, db, True, dt)
+        out[mode] = (dx, dg, db)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(out["1"][1], out["0"][1], rtol=2e-5, atol=2e-4)
+    torch.testing.assert_close(out["1"][2], out["0"][2], rtol=2e-5, atol=2e-4)
+    d = (out["1"][0].float() - out["0"][0].float()).abs()
+    assert float(d.max()) <= 2.0 ** -7 * float(out["0"][0].float().abs().max()) and float((d > 0).float().mean()) < 1e-3
+    # against torch autograd in fp64 (first group)
+    xr = x[:rpg].double().cpu().view(rpg, C, 1, 1).requires_grad_(True)
+    z = F.batch_norm(xr, None, None, gamma.double().cpu(), beta.double().cpu(), True, 0.1, 1e-5)
+    a = F.leaky_relu(z, slope) if act == 2 else F.relu(z)
+    (dx_ref,) = torch.autograd.grad(a, xr, dy[:rpg].double().cpu().view(rpg, C, 1, 1))
+    torch.testing.assert_close(out["1"][0][:rpg].double().cpu(), dx_ref.view(rpg, C), rtol=5e-2, atol=5e-2)

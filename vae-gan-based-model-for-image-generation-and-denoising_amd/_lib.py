@@ -109,6 +109,7 @@ SIGNATURES = {
     "vg_bn_backward_finalize": (c_int, [_P, _I, _I, _L, _P, _P, _P, _P, _I, _P, _P]),
     "vg_bn_finalize_act_forward_supported": (c_int, [_I, _I, _I, _L, _I]),
     "vg_bn_finalize_act_forward": (c_int, [_P, _P, _P, _I, _I, _I, _L, _P, _P, _P, _P, _F, _F, _P, _I, _F, _I, _P]),
+    "vg_bn_backward_finalize_apply": (c_int, [_P, _P, _P, _P, _I, _I, _I, _L, _P, _P, _P, _P, _I, _I, _F, _I, _P]),
     "vg_bn_act_backward_apply": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _I, _L, _L, _I, _P]),
     "vg_act_backward": (c_int, [_P, _P, _P, _L, _I, _F, _I, _P]),
     "vg_bias_grad": (c_int, [_P, _L, _I, _I, _P, _I, _P, _I, _I, _P]),

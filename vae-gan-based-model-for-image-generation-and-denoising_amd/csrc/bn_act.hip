@@ -502,6 +502,96 @@ inline bool bn_fin_fwd_ok(int nparts_per_group, int groups, int C, int64_t rows,
            nparts_per_group > 0 && nparts_per_group <= FF_MAXPARTS && rows * C * 2 <= FF_MAXBYTES;
 }
 
+// ---- backward twin: bn_bwd_finalize_grouped + bn_act_bwd_apply in one launch (same eligibility, same structure) ----
+// Every workgroup sums the column-reduce partials (sum dz | sum dz * xhat) of its group for its 64 channels, forms the
+// three coefficients of bn_bwd_finalize_grouped_kernel and applies dx = a * dz - b * xhat - c; the workgroups of row
+// block 0 accumulate dgamma / dbeta, group after group.
+__global__ __launch_bounds__(FF_TH) void bn_bwd_fin_apply_kernel(
+    const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy, uint16_t* __restrict__ dx,
+    const float* __restrict__ partial, int nparts, int groups, int C, double count, const float* __restrict__ gamma,
+    const float* __restrict__ coeffs, float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
+    int64_t rows_per_group, int rows_per_block, int act, float slope) {
+    __shared__ double red[FF_PL][FF_CH][2];
+    __shared__ float s_co[7][FF_CH];                            // mean | invstd | scale | shift | a | b | c
+    const int tid = threadIdx.x, ch = tid & (FF_CH - 1), pl = tid / FF_CH;
+    const int c0 = blockIdx.y * FF_CH, grp = blockIdx.z;
+    const bool lead = tid < FF_CH && c0 + ch < C;
+    const float gm = (lead && gamma) ? gamma[c0 + ch] : 1.f;
+    auto slice_sums = [&](int g, double& s1, double& s2) {
+        const float* pp = partial + (int64_t)g * nparts * 2 * C;
+        double a = 0.0, b = 0.0;
+        for (int p = pl; p < nparts; p += FF_PL) {
+            a += (double)pp[((int64_t)p * 2 + 0) * C + c0 + ch];
+            b += (double)pp[((int64_t)p * 2 + 1) * C + c0 + ch];
+        }
+        red[pl][ch][0] = a;
+        red[pl][ch][1] = b;
+        __syncthreads();
+        s1 = 0.0; s2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < FF_PL; ++k) { s1 += red[k][ch][0]; s2 += red[k][ch][1]; }
+        __syncthreads();
+    };
+    auto publish_coef = [&](int g, double s1, double s2) {      // lead threads: this group's coefficients into LDS
+        const float* co = coeffs + (int64_t)g * 4 * C + c0 + ch;
+        const float is = co[C];
+        const float a = gm * is;
+        s_co[0][ch] = co[0]; s_co[1][ch] = is; s_co[2][ch] = co[2 * C]; s_co[3][ch] = co[3 * C];
+        s_co[4][ch] = a;
+        s_co[5][ch] = (float)((double)a * s2 / count);
+        s_co[6][ch] = (float)((double)a * s1 / count);
+    };
+    if (blockIdx.x == 0 && grp == 0) {
+        float dg = (lead && dgamma && accumulate) ? dgamma[c0 + ch] : 0.f;
+        float db = (lead && dbeta && accumulate) ? dbeta[c0 + ch] : 0.f;
+        for (int g = 0; g < groups; ++g) {                      // dgamma / dbeta accumulate in group order
+            double s1, s2;
+            slice_sums(g, s1, s2);
+            if (lead) {
+                if (g == 0) publish_coef(0, s1, s2);            // this workgroup applies group 0's rows
+                const bool acc = accumulate || g > 0;
+                dg = acc ? dg + (float)s2 : (float)s2;
+                db = acc ? db + (float)s1 : (float)s1;
+            }
+        }
+        if (lead) {
+            if (dgamma) dgamma[c0 + ch] = dg;
+            if (dbeta) dbeta[c0 + ch] = db;
+        }
+    } else {
+        double s1, s2;
+        slice_sums(grp, s1, s2);
+        if (lead) publish_coef(grp, s1, s2);
+    }
+    __syncthreads();
+    const int u8 = (tid & 7) * 8, rl = tid >> 3;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < rows_per_group ? r0 + rows_per_block : rows_per_group;
+    const int64_t base = (int64_t)grp * rows_per_group;
+    if (c0 + u8 < C) {
+        for (int64_t r = r0 + rl; r < r1; r += FF_TH / 8) {
+            const int64_t off = (base + r) * C + c0 + u8;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(x + off);
+            const u32x4 gq = *reinterpret_cast<const u32x4*>(dy + off);
+            u32x4 o;
+#pragma unroll
+            for (int k2 = 0; k2 < 4; ++k2) {
+                float ov[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int k = u8 + 2 * k2 + h;
+                    const float yv = __uint_as_float(h ? (v[k2] & 0xffff0000u) : (v[k2] << 16));
+                    const float gr = __uint_as_float(h ? (gq[k2] & 0xffff0000u) : (gq[k2] << 16));
+                    ov[h] = s_co[4][k] * act_bwd(s_co[2][k] * yv + s_co[3][k], gr, act, slope) -
+                            s_co[5][k] * ((yv - s_co[0][k]) * s_co[1][k]) - s_co[6][k];
+                }
+                o[k2] = (uint32_t)ElemT<VG_BF16>::from_f32(ov[0]) | ((uint32_t)ElemT<VG_BF16>::from_f32(ov[1]) << 16);
+            }
+            *reinterpret_cast<u32x4*>(dx + off) = o;
+        }
+    }
+}
+
 template <int DT>
 __global__ __launch_bounds__(256) void act_bwd_kernel(const void* __restrict__ x, const void* __restrict__ dy,
                                                       void* __restrict__ dx, int64_t nvec, int act, float slope) {
@@ -665,6 +755,27 @@ extern "C" int vg_bn_finalize_act_forward(const void* x, void* y, const float* s
                        reinterpret_cast<const uint16_t*>(x), reinterpret_cast<uint16_t*>(y), stats, nparts_per_group, groups,
                        C, (double)rpg, gamma, beta, running_mean, running_var, momentum, eps, coeffs, rpg, (int)rpb, act,
                        slope);
+    return VG_LAUNCH_RC();
+}
+
+extern "C" int vg_bn_backward_finalize_apply(const void* x, const void* dy, void* dx, const float* partial,
+                                             int nparts_per_group, int groups, int C, int64_t rows, const float* gamma,
+                                             const float* coeffs, float* dgamma, float* dbeta, int accumulate, int act,
+                                             float slope, int dtype, void* stream) {
+    VG_CHECK_ARG(x && dy && dx && partial && coeffs && rows > 0 && C > 0, VG_EINVAL);
+    VG_CHECK_ARG(vg_aligned16(x) && vg_aligned16(dy) && vg_aligned16(dx), VG_EALIGN);
+    if (!bn_fin_fwd_ok(nparts_per_group, groups, C, rows, dtype)) return VG_ENOSUP;
+    const int64_t rpg = rows / groups;
+    const int slices = C / FF_CH;
+    int64_t want = 512 / (slices * groups);
+    if (want < 1) want = 1;
+    int64_t rpb = (rpg + want - 1) / want;
+    rpb = (rpb + 127) / 128 * 128;
+    const int rb = (int)((rpg + rpb - 1) / rpb);
+    hipLaunchKernelGGL(bn_bwd_fin_apply_kernel, dim3(rb, slices, groups), dim3(FF_TH), 0, vg_stream(stream),
+                       reinterpret_cast<const uint16_t*>(x), reinterpret_cast<const uint16_t*>(dy),
+                       reinterpret_cast<uint16_t*>(dx), partial, nparts_per_group, groups, C, (double)rpg, gamma, coeffs,
+                       dgamma, dbeta, accumulate, rpg, (int)rpb, act, slope);
     return VG_LAUNCH_RC();
 }
 

@@ -531,6 +531,15 @@ def bn_act_backward(x, dy, coeffs, rows, C, count, gamma, act, slope, dgamma, db
                                           coeffs[0, 3].data_ptr(), coeffs[0, 0].data_ptr(), coeffs[0, 1].data_ptr(),
                                           rows, C, act, slope, partial.data_ptr(), cap, byref(n), groups, 4 * C, dtype,
                                           L.stream_ptr()), "vg_bn_act_backward_reduce")
+    if sync is None and BINDING != "torchops" and x.shape[-1] == C and \
+            lib.vg_bn_finalize_act_forward_supported(n.value, groups, C, rows, dtype):
+        # small layer: finalize + apply in one launch (bn_act.hip bn_bwd_fin_apply_kernel); n = partial rows PER GROUP
+        dx = torch.empty_like(x)
+        L.check(lib.vg_bn_backward_finalize_apply(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), partial.data_ptr(),
+                                                  n.value, groups, C, rows, L.ptr(gamma), coeffs.data_ptr(),
+                                                  L.ptr(dgamma), L.ptr(dbeta), 1 if accumulate else 0, act, slope, dtype,
+                                                  L.stream_ptr()), "vg_bn_backward_finalize_apply")
+        return dx
     coef = torch.empty(groups, 3, C, dtype=torch.float32, device=x.device)
     if sync is not None:
         lsums = torch.empty(groups, 2, C, dtype=torch.float64, device=x.device)
