@@ -498,8 +498,7 @@ def bn_finalize_act_forward(x, stats, nparts, C, rows, gamma, beta, running_mean
     (bn_act.hip bn_fin_act_fwd_kernel).  Returns (coeffs [groups][4][C], y), or None when the shape does not qualify
     (the caller then runs bn_finalize + bn_act_forward)."""
     lib = L.load()
-    if BINDING == "torchops" or x.shape[-1] != C or \
-            not lib.vg_bn_finalize_act_forward_supported(nparts // groups, groups, C, rows, dtype):
+    if x.shape[-1] != C or not lib.vg_bn_finalize_act_forward_supported(nparts // groups, groups, C, rows, dtype):
         return None
     _need_cuda(x, stats)
     co = torch.empty(groups, 4, C, dtype=torch.float32, device=x.device)
@@ -531,7 +530,7 @@ def bn_act_backward(x, dy, coeffs, rows, C, count, gamma, act, slope, dgamma, db
                                           coeffs[0, 3].data_ptr(), coeffs[0, 0].data_ptr(), coeffs[0, 1].data_ptr(),
                                           rows, C, act, slope, partial.data_ptr(), cap, byref(n), groups, 4 * C, dtype,
                                           L.stream_ptr()), "vg_bn_act_backward_reduce")
-    if sync is None and BINDING != "torchops" and x.shape[-1] == C and \
+    if sync is None and x.shape[-1] == C and \
             lib.vg_bn_finalize_act_forward_supported(n.value, groups, C, rows, dtype):
         # small layer: finalize + apply in one launch (bn_act.hip bn_bwd_fin_apply_kernel); n = partial rows PER GROUP
         dx = torch.empty_like(x)
