@@ -132,3 +132,27 @@ def test_validation_epoch_over_the_resident_loader_vs_oracle(jpeg_folder):
     V.configure_seed(7)
     b = V.validation_epoch(e, g, vl)
     assert a == b and a != c and all(np.isfinite(v) for v in a.values())
+
+
+def test_loader_bound_to_the_graph_input_trains_identically_without_the_copy(jpeg_folder):
+    """Zero-copy hand-off: DeviceLoader.bind_output(trainer.graph_input()) assembles each full batch straight into the
+    buffer the captured iteration reads; the losses equal those of the unbound loader bit for bit."""
+    runs = []
+    for bound in (False, True):
+        V.configure_seed(42)
+        tl, _, shape = V.data.get_dataset_loaders(jpeg_folder, batch_size=16, device=DEV, workers=1)
+        e, g, d, tr = build(shape[1])
+        losses = []
+        for epoch in range(3):                                    # epoch 0: eager warm-up + capture; then replays
+            for real in tl:
+                if real.shape[0] != 16:
+                    continue                                      # the ragged last batch would need its own graph
+                if bound and tr.graph_input() is not None and getattr(tl, "_out", None) is None:
+                    tl.bind_output(tr.graph_input())
+                out = tr.train_step_graphed(real, 60)
+                losses.append(out[:5].clone())
+                if bound and getattr(tl, "_out", None) is not None and epoch == 2:
+                    assert real.data_ptr() == tr.graph_input().data_ptr()
+        torch.cuda.synchronize()
+        runs.append(torch.stack(losses).cpu())
+    assert torch.equal(runs[0], runs[1])

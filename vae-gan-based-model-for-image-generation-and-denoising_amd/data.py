@@ -152,12 +152,20 @@ class DeviceLoader:
             perm = torch.arange(n)
         return self.indices[perm]
 
+    def bind_output(self, out: Optional[torch.Tensor]) -> None:
+        """Assemble every FULL batch into `out` ([B, C, H, W] f32 on the device, e.g. VAEGANTrainer.graph_input()) and
+        yield that same tensor: the consumer must be done with a batch before asking for the next (a training loop
+        is).  A ragged last batch gets its own tensor.  None unbinds."""
+        self._out = out
+
     def __iter__(self) -> Iterator[torch.Tensor]:
         order = self.epoch_order()
         self.last_order = order
         dev_order = order.to(self.dataset.images.device)                   # one small H2D copy per epoch
+        out = getattr(self, "_out", None)
         for lo, hi in self.global_batches(order.numel()):
-            yield self.dataset.batch(dev_order[lo:hi])
+            idx = dev_order[lo:hi]
+            yield self.dataset.batch(idx, out if (out is not None and out.shape[0] == idx.numel()) else None)
 
 
 def get_dataset_loaders(path, batch_size=64, train_p=0.9, dataset_size=None, device="cuda", rank=0, world=1,

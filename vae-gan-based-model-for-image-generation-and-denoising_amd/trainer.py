@@ -242,6 +242,12 @@ class VAEGANTrainer:
         return losses
 
     # ---- hipGraph replay of the whole iteration -------------------------------------------------------------
+    def graph_input(self):
+        """The static image buffer the captured iteration reads ([B, C, H, W] f32), or None before a capture.  A loader
+        that assembles its batches straight into it (data.DeviceLoader.bind_output) hands them to train_step_graphed
+        without the device-to-device copy; pass the SAME tensor as `real`."""
+        return None if self._graph is None else self._graph[3][0]
+
     def train_step_graphed(self, real: torch.Tensor, epoch: int, eps_z: Optional[torch.Tensor] = None,
                            eps_real: Optional[torch.Tensor] = None,
                            eps_recon: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -262,7 +268,8 @@ class VAEGANTrainer:
         key = self._capture_key(real, epoch, inject)
         if self._graph is not None and self._graph[0] == key:
             _, graphs, cuts, sin, sout = self._graph
-            sin[0].copy_(real)
+            if real.data_ptr() != sin[0].data_ptr():    # a batch assembled in graph_input() needs no copy
+                sin[0].copy_(real)
             if inject:
                 sin[1].copy_(eps_z), sin[2].copy_(eps_real), sin[3].copy_(eps_recon)
             self._replay(graphs, cuts)
