@@ -165,7 +165,10 @@ class DeviceLoader:
         out = getattr(self, "_out", None)
         for lo, hi in self.global_batches(order.numel()):
             idx = dev_order[lo:hi]
-            yield self.dataset.batch(idx, out if (out is not None and out.shape[0] == idx.numel()) else None)
+            if out is not None and out.shape[0] == idx.numel():
+                yield self.dataset.batch(idx, out)
+            else:
+                yield self.dataset.batch(idx)
 
 
 def get_dataset_loaders(path, batch_size=64, train_p=0.9, dataset_size=None, device="cuda", rank=0, world=1,
