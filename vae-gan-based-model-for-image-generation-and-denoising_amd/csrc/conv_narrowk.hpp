@@ -15,7 +15,11 @@
 //   * bias, (Leaky)ReLU of a BatchNorm-less layer and the per-channel BatchNorm partial sums ride in the epilogue,
 //     one slab row per workgroup exactly as gg_kernel emits them (bn_act.hip reads either).
 
-constexpr int NK_BM = 256;
+#ifndef VG_NK_GP
+#define VG_NK_GP 4
+#endif
+constexpr int NK_GP = VG_NK_GP;        // 16-pixel MFMA row groups per wave (4: 204 VGPRs at N=64, K=128 -> 2 waves per SIMD)
+constexpr int NK_BM = 64 * NK_GP;
 
 inline bool narrowk_enabled() {
     const char* e = getenv("VG_EDGE");
@@ -45,11 +49,11 @@ template <int NT, int KC>     // N = 16 * NT output channels, Kp = 32 * KC
 __global__ __launch_bounds__(256) void ggn_kernel(const vg_gg_desc d) {
     // per-wave C staging [64 pixels][N] bf16 (+16 B pad per pixel row) | stats scratch [4 waves][N][2]
     constexpr int N = NT * 16, CP = N * 2 + 16;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 64 * CP + 4 * N * 2 * 4];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 16 * NK_GP * CP + 4 * N * 2 * 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     const int M = d.B * d.GH * d.GW, GHW = d.GH * d.GW;
-    const int m0 = blockIdx.x * NK_BM + wave * 64;
+    const int m0 = blockIdx.x * NK_BM + wave * 16 * NK_GP;
     const int ntap = d.TH * d.TW;
     // no integer divisions in the address generation (they, not the loads, were the critical path of the first cut):
     // m -> (b, gy, gx) through float reciprocals (m < 2^24), tap -> (ta, tb) through an 8-bit fixed-point reciprocal
@@ -68,9 +72,9 @@ __global__ __launch_bounds__(256) void ggn_kernel(const vg_gg_desc d) {
 
     // ---- A fragments: lane (fr, fg) = (pixel m0 + 16g + fr, tap 4kc + fg) -> one 16-byte input pixel ----
     const unsigned char* Xb = reinterpret_cast<const unsigned char*>(d.X);
-    u32x4 a[4][KC];
+    u32x4 a[NK_GP][KC];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
+    for (int g = 0; g < NK_GP; ++g) {
         const int m = m0 + g * 16 + fr;
         int b = 0, gy = -(1 << 20), gx = 0;
         if (m < M) {
@@ -91,9 +95,9 @@ __global__ __launch_bounds__(256) void ggn_kernel(const vg_gg_desc d) {
             a[g][kc] = v;
         }
     }
-    f32x4 acc[4][NT];
+    f32x4 acc[NK_GP][NT];
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+    for (int g = 0; g < NK_GP; ++g)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             f32x4 c = {0.f, 0.f, 0.f, 0.f};
@@ -108,7 +112,7 @@ __global__ __launch_bounds__(256) void ggn_kernel(const vg_gg_desc d) {
     for (int nt = 0; nt < NT; ++nt) {
         const float bv = d.bias != nullptr ? d.bias[nt * 16 + fr] : 0.f;
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+        for (int g = 0; g < NK_GP; ++g)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float v = acc[g][nt][r] + bv;
@@ -117,12 +121,12 @@ __global__ __launch_bounds__(256) void ggn_kernel(const vg_gg_desc d) {
             }
     }
     if (d.stats != nullptr) {
-        float* red = reinterpret_cast<float*>(smem + 4 * 64 * CP);          // [wave][N][2]
+        float* red = reinterpret_cast<float*>(smem + 4 * 16 * NK_GP * CP);  // [wave][N][2]
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
+            for (int g = 0; g < NK_GP; ++g)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (m0 + g * 16 + fg * 4 + r < M) {
@@ -147,9 +151,9 @@ __global__ __launch_bounds__(256) void ggn_kernel(const vg_gg_desc d) {
         }
     }
     // C tile: each wave transposes its own 64 x N block through LDS and writes one contiguous run of the output
-    unsigned char* cw = smem + wave * 64 * CP;
+    unsigned char* cw = smem + wave * 16 * NK_GP * CP;
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+    for (int g = 0; g < NK_GP; ++g)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(256) void ggn_kernel(const vg_gg_desc d) {
     constexpr int SEGS = N * 2 / 16;                                          // 16-byte segments per pixel
     unsigned char* Yb = reinterpret_cast<unsigned char*>(d.Y);
 #pragma unroll
-    for (int u = lane; u < 64 * SEGS; u += 64) {
+    for (int u = lane; u < 16 * NK_GP * SEGS; u += 64) {
         const int row = u / SEGS, seg = u - row * SEGS;
         const int m = m0 + row;
         if (m < M)
