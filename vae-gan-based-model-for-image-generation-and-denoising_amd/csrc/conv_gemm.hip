@@ -706,6 +706,11 @@ inline bool patch32() {                     // patch variant for 32-output-chann
     return e ? atoi(e) != 0 : true;
 }
 
+inline bool patch_nr3() {                   // 128 x 64 patch kernel with 3 patch rounds (40 KB LDS: 4 workgroups per CU); per call
+    const char* e = getenv("VG_GG_PATCH_NR3");
+    return e ? atoi(e) != 0 : true;
+}
+
 inline int patch256_min() {
     const char* e = getenv("VG_PATCH256_MIN");
     return e ? atoi(e) : 256;               // 256 x 128 tiles where every CU gets at least one (step sweep: 128 / 192 / 256 / 384 -> 38.3 / 38.6 / 38.7 / 38.7k img/s)
@@ -898,6 +903,7 @@ extern "C" int vg_gather_gemm(const vg_gg_desc* d, int dtype, void* stream) {
         pg.n_major = n_major(d, n_tiles, 2) ? 1 : 0;
         if (t.bm == 256 && t.bn == 64) vg_launch_timed(0, (ggp_kernel<4, 64>), grid, dim3(512), 0, vg_stream(stream), *d, pg);
         else if (t.bm == 256) vg_launch_timed(0, ggp_kernel<4>, grid, dim3(512), 0, vg_stream(stream), *d, pg);
+        else if (t.bn == 64 && pg.NPP <= 192 && patch_nr3()) vg_launch_timed(0, (ggp_kernel<2, 64, 3>), grid, dim3(256), 0, vg_stream(stream), *d, pg);
         else if (t.bn == 64) vg_launch_timed(0, (ggp_kernel<2, 64>), grid, dim3(256), 0, vg_stream(stream), *d, pg);
         else if (t.bn == 32) vg_launch_timed(0, (ggp_kernel<2, 32>), grid, dim3(256), 0, vg_stream(stream), *d, pg);
         else vg_launch_timed(0, ggp_kernel<2>, grid, dim3(256), 0, vg_stream(stream), *d, pg);

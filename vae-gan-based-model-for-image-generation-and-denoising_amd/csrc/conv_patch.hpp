@@ -46,11 +46,11 @@ __device__ __forceinline__ void gp_wait(int n) {
 //         History: with a 128-register cap (two workgroups per CU) it spilled and lost 30 %; at one workgroup per CU
 //         with two taps per barrier it was on par; with four taps per barrier it wins where the launch has >= 384
 //         tiles (G3 fprop 742 -> 780, G4 dgrad 689 -> 750 TFLOP/s) and loses at 256 tiles (G2 fprop 835 -> 806).
-template <int WM, int BN = GP_BN>
+template <int WM, int BN = GP_BN, int NR_ = 0>       // NR_: patch DMA rounds (0 = by tile shape); 3 where the patch has <= 192 pixels
 __global__ __launch_bounds__(128 * WM, WM == 4 ? 2 : 1) void ggp_kernel(const vg_gg_desc d, const PatchGeo g) {
     // BN = 128: wave tile 64 x 64; BN = 64 (layers with <= 64 output channels): wave tile 64 x 32; BN = 32: 64 x 16
     constexpr int BM = 64 * WM, WN = 2, TM = 4, TN = BN / 32, NT = 128 * WM, BST = BN * 64, WNC = BN / 2;
-    constexpr int NR = (WM == 4 || GP_TPS != 2) ? 3 : 4;   /* WM == 4: 3 rounds of 512 lanes = 384 pixels */   // patch DMA rounds: 192 (3) or 256 (4) pixels per 128 rows
+    constexpr int NR = NR_ ? NR_ : ((WM == 4 || GP_TPS != 2) ? 3 : 4);   /* WM == 4: 3 rounds of 512 lanes = 384 pixels */   // patch DMA rounds: 192 (3) or 256 (4) pixels per 128 rows
     constexpr int GP_PBUF = NR * NT * 16;           // NR rounds of NT lanes x 16 B
     constexpr int TPS = (WM == 4 && GP_TPS == 2) ? 4 : GP_TPS;   // 8 waves, one workgroup per CU: all 4 taps per barrier
     constexpr int NB = TPS == 2 ? 2 : 3, BSTAGE = TPS * BST;
