@@ -38,6 +38,49 @@ __global__ __launch_bounds__(256) void randn_fill_kernel(float* __restrict__ out
 }
 
 // ---- NCHW f32  <->  NHWC (dtype, channels padded to CP) ----------------------------------------
+// Four consecutive pixels of a row per thread (HW % 4 == 0, CP == 8, C <= 4, 16-byte aligned planes): float4 loads of
+// every channel plane, ONE Philox block per channel for the four pixels' noise, four 16-byte pixel stores.
+template <int DT>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_x4_kernel(const float* __restrict__ x, const NoiseSrc eps, float sigma,
+                                                              void* __restrict__ y, int64_t npix4, int C, int HW,
+                                                              float lo, float hi, float* __restrict__ y_nchw) {
+    static_assert(DT == VG_BF16, "8 bf16 channels = one 16-byte pixel");
+    const bool noisy = eps.eps != nullptr || eps.rng != nullptr;
+    for (int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i4 < npix4; i4 += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = i4 * 4;
+        const int64_t b = i / HW;
+        const int64_t hw = i - b * HW;
+        float v[4][4];                                          // [pixel][channel]
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c < C) {
+                const int64_t src = (b * C + c) * HW + hw;
+                const float4 t4 = *reinterpret_cast<const float4*>(x + src);
+                float t[4] = {t4.x, t4.y, t4.z, t4.w};
+                if (noisy) {
+                    const Normal4 nz = noise4_at(eps, src);
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) t[p] = t[p] + sigma * nz.v[p];
+                }
+#pragma unroll
+                for (int p = 0; p < 4; ++p) { t[p] = fminf(fmaxf(t[p], lo), hi); v[p][c] = t[p]; }
+                if (y_nchw) *reinterpret_cast<float4*>(y_nchw + src) = float4{t[0], t[1], t[2], t[3]};
+            } else {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) v[p][c] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            u32x4 o;
+            o[0] = (uint32_t)ElemT<VG_BF16>::from_f32(v[p][0]) | ((uint32_t)ElemT<VG_BF16>::from_f32(v[p][1]) << 16);
+            o[1] = (uint32_t)ElemT<VG_BF16>::from_f32(v[p][2]) | ((uint32_t)ElemT<VG_BF16>::from_f32(v[p][3]) << 16);
+            o[2] = 0u; o[3] = 0u;
+            *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(y) + (i + p) * 16) = o;
+        }
+    }
+}
+
 template <int DT>
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, const NoiseSrc eps,
                                                            float sigma, void* __restrict__ y, int64_t npix, int C,
@@ -490,6 +533,12 @@ extern "C" int vg_nchw_to_nhwc_rng(const float* x, const uint64_t* rng, int draw
     CHECK_DT();
     VG_CHECK_ARG(x && rng && y && draw >= 0 && draw < 256 && B > 0 && C > 0 && H > 0 && W > 0 && CP >= C && CP % 4 == 0, VG_EINVAL);
     const int64_t npix = (int64_t)B * H * W;
+    if (dtype == VG_BF16 && CP == 8 && C <= 4 && (H * W) % 4 == 0 && vg_aligned16(x) && vg_aligned16(y)) {
+        hipLaunchKernelGGL(nchw_to_nhwc_x4_kernel<VG_BF16>, dim3(blocks_for(npix / 4)), dim3(256), 0, vg_stream(stream), x,
+                           (NoiseSrc{nullptr, (const unsigned long long*)rng, (uint32_t)draw}), sigma, y, npix / 4, C, H * W,
+                           -3.0e38f, 3.0e38f, (float*)nullptr);
+        return VG_LAUNCH_RC();
+    }
     DISPATCH_DT(nchw_to_nhwc_kernel, dim3(blocks_for(npix)), dim3(256), vg_stream(stream), x,
                 (NoiseSrc{nullptr, (const unsigned long long*)rng, (uint32_t)draw}), sigma, y, npix, C, H * W, CP, -3.0e38f, 3.0e38f,
                 (float*)nullptr);
