@@ -380,7 +380,8 @@ int vg_ssim(const float* a, const float* b, int B, int C, int H, int W, float* o
  * reparameterisation, :91 instance noise on the real batch, :92 on the reconstruction) generated where they are
  * consumed instead of being materialised by a separate generator launch.
  * rng: device memory, two 64-bit words {seed, iteration counter}.  Counter-based Philox4x32-10 keyed by the seed;
- * counter = (element index in the reference's NCHW / [B][L] order, draw id 0..255, iteration counter); Box-Muller.
+ * counter = (element index >> 2 in the reference's NCHW / [B][L] order, draw id 0..255, iteration counter); one block
+ * gives four normals (two Box-Muller pairs, cosine and sine of each): element i is component i & 3 of block i >> 2.
  * The `_rng` forms of the consuming kernels are identical to their eps-pointer forms with
  * eps[i] = N(seed, iteration, draw, i); vg_randn materialises exactly that tensor (tests, and callers that want
  * the draw itself).  vg_rng_advance (one thread) bumps the iteration counter: launch it once at the top of every
