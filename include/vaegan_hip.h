@@ -48,8 +48,9 @@ extern "C" {
 #define VG_ACT_LRELU   2   /* nn.LeakyReLU(slope)    main_vae.py:25, gan_code.py:62-82 */
 #define VG_ACT_TANH    3   /* nn.Tanh()              gan_code.py:50 (vg_tnconv epilogue only) */
 
-#define VG_ABI_VERSION 4   /* 2: vg_pack_desc.tile_start, SyncBN / WGAN / data-path entry points; 3: in-kernel noise (vg_*_rng);
-                             4: vg_bn_finalize_act_forward, vg_bn_backward_finalize_apply */
+#define VG_ABI_VERSION 5   /* 2: vg_pack_desc.tile_start, SyncBN / WGAN / data-path entry points; 3: in-kernel noise (vg_*_rng);
+                             4: vg_bn_finalize_act_forward, vg_bn_backward_finalize_apply;
+                             5: input prologue of vg_tn_desc / vg_ew_desc */
 int vg_abi_version(void);
 /* Live kernel timing for the roofline report: while enabled, gather-GEMM (family 0) and wgrad (family 1)
  * launches carry a HIP start/stop event pair on their stream (hipExtLaunchKernelGGL); collect() synchronises,
@@ -284,6 +285,13 @@ typedef struct vg_tn_desc {
     int32_t draw;
     float sigma;
     int32_t B, IH, IW, C, N, K, S, P, OH, OW, OC, Wpitch, act;
+    /* input prologue (ABI 5): X is the RAW output of the layer below and the kernel applies that layer's BatchNorm +
+     * activation while loading it, x' = act_in(in_scale[c] * x + in_shift[c]) rounded to bf16 -- bit for bit what
+     * vg_bn_act_forward would have stored, without the pass.  in_scale == NULL: X is used as it is. */
+    const float* in_scale;
+    const float* in_shift;
+    int32_t in_act;
+    float in_slope;
 } vg_tn_desc;
 /* Weight gradient of the edge layers, bf16 operands, f32 result:
  *     dW[c*s_c + n*s_n + kh*K + kw] (+)= sum_{b,py,px} Wd[b][py][px][c] * Nr[b][py*S - P + kh][px*S - P + kw][n]
@@ -301,6 +309,11 @@ typedef struct vg_ew_desc {
     int64_t ws_bytes;
     const void* zeros;
     int32_t B, WH, WW, C, NH, NW, N, K, S, P, s_c, s_n, accumulate;
+    /* prologue on the WIDE operand (ABI 5), as vg_tn_desc: Wd' = act_in(in_scale[c] * Wd + in_shift[c]) */
+    const float* in_scale;
+    const float* in_shift;
+    int32_t in_act;
+    float in_slope;
 } vg_ew_desc;
 int64_t vg_edge_wgrad_ws_bytes(const vg_ew_desc* d);
 int vg_edge_wgrad(const vg_ew_desc* d, void* stream);

@@ -726,3 +726,44 @@ def test_bn_backward_finalize_and_apply_in_one_launch(ops, monkeypatch, rpg, C, 
     a = F.leaky_relu(z, slope) if act == 2 else F.relu(z)
     (dx_ref,) = torch.autograd.grad(a, xr, dy[:rpg].double().cpu().view(rpg, C, 1, 1))
     torch.testing.assert_close(out["1"][0][:rpg].double().cpu(), dx_ref.view(rpg, C), rtol=5e-2, atol=5e-2)
+
+
+def test_edge_kernels_apply_the_batchnorm_of_the_layer_below_on_their_loads(ops):
+    """vg_tnconv / vg_edge_wgrad input prologue: fed the RAW output of the layer below plus its BatchNorm scale / shift
+    and activation, they must give bit for bit what they give on the tensor vg_bn_act_forward stores."""
+    dt = G.BF16
+    B, H, C, N = 4, 64, 64, 3
+    g = torch.Generator().manual_seed(11)
+    y = (torch.randn(B, H, H, C, generator=g) * 1.2 + 0.3).to(DEV).to(torch.bfloat16)
+    scale = (torch.rand(C, generator=g) + 0.5).to(DEV)
+    shift = (torch.randn(C, generator=g) * 0.3).to(DEV)
+    co = torch.stack([torch.zeros(C, device=DEV), torch.ones(C, device=DEV), scale, shift]).unsqueeze(0).contiguous()
+    a = ops.bn_act_forward(y, co, B * H * H, C, 1, 0.0, dt)                       # ReLU, as the Generator's blocks
+    tn, pk = G.convT_fprop_tn(B, H, H, C, N, 3, 1, 1, dt)
+    w = torch.randn(C, N, 3, 3, generator=g).to(DEV) * 0.1
+    Wp = ops.pack_weights(pk, w, dt)
+    Y1, I1 = ops.tnconv(tn, a, Wp, want_nchw=True, act=3)
+    Y2, I2 = ops.tnconv(tn, y, Wp, want_nchw=True, act=3, pre=(scale, shift, 1, 0.0))
+    assert torch.equal(Y1, Y2) and torch.equal(I1, I2)
+    ew = G.convT_wgrad_edge(B, H, H, C, N, 3, 1, 1, dt)
+    dimg = torch.randn(B, H, H, 8, generator=g).to(DEV).to(torch.bfloat16)
+    dimg[..., N:] = 0
+    d1, d2 = torch.zeros_like(w), torch.zeros_like(w)
+    ops.edge_wgrad(ew, a, dimg, d1, False)
+    ops.edge_wgrad(ew, y, dimg, d2, False, pre=(scale, shift, 1, 0.0))
+    assert torch.equal(d1, d2)
+    # LeakyReLU prologue and a 32-channel wide operand
+    C2 = 32
+    y2 = torch.randn(B, H, H, C2, generator=g).to(DEV).to(torch.bfloat16)
+    sc2, sh2 = (torch.rand(C2, generator=g) + 0.5).to(DEV), (torch.randn(C2, generator=g) * 0.3).to(DEV)
+    co2 = torch.stack([torch.zeros(C2, device=DEV), torch.ones(C2, device=DEV), sc2, sh2]).unsqueeze(0).contiguous()
+    a2 = ops.bn_act_forward(y2, co2, B * H * H, C2, 2, 0.2, dt)
+    tn2, pk2 = G.convT_fprop_tn(B, H, H, C2, N, 3, 1, 1, dt)
+    w2 = torch.randn(C2, N, 3, 3, generator=g).to(DEV) * 0.1
+    Wp2 = ops.pack_weights(pk2, w2, dt)
+    assert torch.equal(ops.tnconv(tn2, a2, Wp2)[0], ops.tnconv(tn2, y2, Wp2, pre=(sc2, sh2, 2, 0.2))[0])
+    ew2 = G.convT_wgrad_edge(B, H, H, C2, N, 3, 1, 1, dt)
+    e1, e2 = torch.zeros_like(w2), torch.zeros_like(w2)
+    ops.edge_wgrad(ew2, a2, dimg, e1, False)
+    ops.edge_wgrad(ew2, y2, dimg, e2, False, pre=(sc2, sh2, 2, 0.2))
+    assert torch.equal(e1, e2)

@@ -851,3 +851,19 @@ def test_denoise_eval_path_vs_oracle(S, sigma):
     a01, b01 = (recon_ref + 1) / 2, (img + 1) / 2
     assert abs(out["psnr"] - R.psnr(a01, b01)) < 1e-3
     assert abs(out["ssim"] - R.ssim(a01, b01)) < 1e-4
+
+
+def test_edge_prologue_training_iteration_equals_default(monkeypatch):
+    """VG_EDGE_PROLOGUE=1 (the last Generator block's BatchNorm + ReLU applied inside the edge kernels' operand loads, no
+    activated copy) must leave a bf16 training iteration bit-identical: the prologue produces exactly the stored values."""
+    outs = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("VG_EDGE_PROLOGUE", mode)
+        V.configure_seed(42)
+        e, g, d, tr = build(64, dtype="bf16")
+        x = torch.randn(8, 3, 64, 64, generator=torch.Generator().manual_seed(3)).clamp(-1, 1).to(DEV)
+        l1 = tr.train_step(x, 60)[:5].clone()
+        l2 = tr.train_step(x, 60)[:5].clone()
+        torch.cuda.synchronize()
+        outs.append(torch.stack([l1, l2]).cpu())
+    assert torch.equal(outs[0], outs[1])

@@ -16,7 +16,7 @@ VG_F32, VG_BF16, VG_FP8 = 0, 1, 2
 VG_FP8_WSHIFT = 6
 VG_ACT_NONE, VG_ACT_RELU, VG_ACT_LRELU, VG_ACT_TANH = 0, 1, 2, 3
 VG_MAX_PHASE = 4
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _ERR = {-1: "VG_EINVAL (bad shape/size/flag)", -2: "VG_EALIGN (16-byte contract violated)",
         -3: "VG_ENOSUP (unsupported configuration)"}
@@ -55,7 +55,8 @@ class TNDesc(Structure):
                 ("rng", c_void_p), ("draw", c_int32), ("sigma", c_float),
                 ("B", c_int32), ("IH", c_int32), ("IW", c_int32), ("C", c_int32), ("N", c_int32), ("K", c_int32),
                 ("S", c_int32), ("P", c_int32), ("OH", c_int32), ("OW", c_int32), ("OC", c_int32),
-                ("Wpitch", c_int32), ("act", c_int32)]
+                ("Wpitch", c_int32), ("act", c_int32),
+                ("in_scale", c_void_p), ("in_shift", c_void_p), ("in_act", c_int32), ("in_slope", c_float)]
 
 
 class EWDesc(Structure):
@@ -64,7 +65,8 @@ class EWDesc(Structure):
                 ("zeros", c_void_p),
                 ("B", c_int32), ("WH", c_int32), ("WW", c_int32), ("C", c_int32), ("NH", c_int32), ("NW", c_int32),
                 ("N", c_int32), ("K", c_int32), ("S", c_int32), ("P", c_int32), ("s_c", c_int32), ("s_n", c_int32),
-                ("accumulate", c_int32)]
+                ("accumulate", c_int32),
+                ("in_scale", c_void_p), ("in_shift", c_void_p), ("in_act", c_int32), ("in_slope", c_float)]
 
 
 class PackDesc(Structure):

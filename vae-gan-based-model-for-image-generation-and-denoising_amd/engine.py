@@ -219,6 +219,21 @@ class StackEngine:
             self._specs[key] = sp
         return self._specs[key]
 
+    def edge_prologue(self, i: int, B: int, groups: int = 1) -> bool:
+        """Stage i's BatchNorm + activation can ride in stage i+1's kernels (no vg_bn_act_forward pass, no activated
+        copy: 67 MB less activation memory at S=64 B=128): stage i+1 is an edge layer whose forward runs on vg_tnconv and
+        whose weight gradient on vg_edge_wgrad, both of which take an input prologue.  OPT-IN (VG_EDGE_PROLOGUE=1):
+        bit-exact, but measured slower on MI355X (tools/prologue_bench.py, the Generator's last layer: the 29.5 us pass
+        it removes against +15.8 us in vg_tnconv and +46.5 us in vg_edge_wgrad, whose three tap-tile waves each convert
+        every wide fragment: step 2.766 vs 2.742 ms)."""
+        key = (i, B, groups, "edge_prologue")
+        if key not in self._specs:
+            ok = (os.environ.get("VG_EDGE_PROLOGUE", "0") == "1" and groups == 1 and self.dtype == G.BF16 and
+                  i + 1 < len(self.stages) and self.stages[i].bn is not None and self.stages[i + 1].kind == "convT" and
+                  self.tn(i + 1, B, "fprop") is not None and self.edge_wg(i + 1, B) is not None)
+            self._specs[key] = ok
+        return self._specs[key]
+
     # ---- parameter handling ---------------------------------------------------------------------
     def params(self) -> List[torch.Tensor]:
         ps = []
@@ -337,6 +352,7 @@ class StackEngine:
         ctx = []
         a = x
         a8 = None                             # e4m3 twin of `a` when the producing pass already made one (fp8 engines)
+        a_pre = None                          # (scale, shift, act, slope): `a` is RAW, the consumer applies this BatchNorm + act
         Bg, B = B, B * groups
         for i, st in enumerate(self.stages):
             if st.kind == "head":
@@ -353,15 +369,19 @@ class StackEngine:
                 if tail is not None and i == len(self.stages) - 1:
                     Yn, img = ops.tnconv(tnsp, a, packs[i]["tn_fprop"], want_nhwc=tail.get("out_noisy") is not None,
                                          want_nchw=True, act=VG_ACT_TANH, noise=tail.get("noise"),
-                                         sigma=tail.get("sigma", 0.0), out_nhwc=tail.get("out_noisy"), alg=st.alg(B, dt))
+                                         sigma=tail.get("sigma", 0.0), out_nhwc=tail.get("out_noisy"), alg=st.alg(B, dt),
+                                         pre=a_pre)
                     out = img
                     Yshape = (B, st.hout, st.hout, OC)
                 else:
-                    out, _ = ops.tnconv(tnsp, a, packs[i]["tn_fprop"], alg=st.alg(B, dt))
+                    out, _ = ops.tnconv(tnsp, a, packs[i]["tn_fprop"], alg=st.alg(B, dt), pre=a_pre)
                     Yshape = tuple(out.shape)
                 if keep:
-                    ctx.append({"x": a, "Y": None, "Yshape": Yshape, "coeffs": None, "rows": B * st.hout * st.hout, "OC": OC})
-                a, a8 = out, None
+                    # "x" is the RAW output of the stage below when x_pre is set (its BatchNorm + activation ride in this
+                    # stage's kernels: forward above, weight gradient in _param_grads)
+                    ctx.append({"x": a, "x_pre": a_pre, "Y": None, "Yshape": Yshape, "coeffs": None,
+                                "rows": B * st.hout * st.hout, "OC": OC})
+                a, a8, a_pre = out, None, None
                 continue
             gg, pk = self.spec(i, B, "fprop")
             want_stats = st.bn is not None and train
@@ -387,11 +407,13 @@ class StackEngine:
             if want_stats and not epilogue_stats:
                 stats, nparts = ops.channel_stats(Y, rows, OC, dt)
             coeffs = None
+            nxt_pre = None
             if st.bn is not None:
                 bn = st.bn
                 nxt8 = i + 1 < len(self.stages) and self.stages[i + 1].kind != "head" and self.fp8_ok(i + 1)
+                lazy = self.edge_prologue(i, B, groups) and not nxt8 and st.cout == OC
                 fused = None
-                if train and self.bn_sync is None and not nxt8 and st.cout == OC:
+                if train and self.bn_sync is None and not nxt8 and st.cout == OC and not lazy:
                     # small statistics slab: finalize + normalise + activation in one launch
                     fused = ops.bn_finalize_act_forward(Y, stats, nparts, OC, rows, bn.weight.detach(), bn.bias.detach(),
                                                         bn.running_mean, bn.running_var, BN_MOMENTUM, BN_EPS, st.act,
@@ -405,7 +427,10 @@ class StackEngine:
                 else:
                     coeffs = ops.bn_eval_coeffs(bn.weight.detach(), bn.bias.detach(), bn.running_mean,
                                                 bn.running_var, BN_EPS)
-                if fused is not None:
+                if lazy:
+                    # the next stage's edge kernels apply this BatchNorm + activation on their operand loads
+                    out, out8, nxt_pre = Y, None, (coeffs[0, 2], coeffs[0, 3], st.act, st.slope)
+                elif fused is not None:
                     out, out8 = fused[1], None
                 elif nxt8:                                  # the next layer's fp8 operand comes out of this same pass
                     out, out8 = ops.bn_act_forward(Y, coeffs, rows, OC, st.act, st.slope, dt, want_fp8=True)
@@ -415,7 +440,7 @@ class StackEngine:
                 out, out8 = Y, None                         # activation (if any) already applied by the epilogue
             if keep:
                 ctx.append({"x": a, "Y": Y, "coeffs": coeffs, "rows": rows, "OC": OC})
-            a, a8 = out, out8
+            a, a8, a_pre = out, out8, nxt_pre
         if train and any(st.bn is not None for st in self.stages):
             self.pending_bn_ticks += groups
         return a, (ctx, B, train)
@@ -590,11 +615,16 @@ class StackEngine:
         if ew is not None and gw.is_contiguous():
             # wide operand = the many-channel side, narrow = the 3-channel side (conv: dY / input image; convT: input / dY)
             wide, narrow = (dY, c["x"]) if st.kind == "conv" else (c["x"], dY)
-            ops.edge_wgrad(ew, wide, narrow, gw, acc, alg=st.alg(B, dt))
+            ops.edge_wgrad(ew, wide, narrow, gw, acc, alg=st.alg(B, dt), pre=c.get("x_pre") if st.kind == "convT" else None)
         elif st.kind == "conv":
             ops.wgrad(wg, dY, c["x"], gw, acc, dt, alg=st.alg(B, dt))
         else:
-            ops.wgrad(wg, c["x"], dY, gw, acc, dt, alg=st.alg(B, dt))
+            xin = c["x"]
+            if c.get("x_pre") is not None:      # raw input kept for the edge kernel, which was not taken: activate it now
+                sc, sh, act_, slope_ = c["x_pre"]
+                co = torch.stack([torch.zeros_like(sc), torch.zeros_like(sc), sc, sh]).unsqueeze(0).contiguous()
+                xin = ops.bn_act_forward(xin, co, xin.numel() // xin.shape[-1], xin.shape[-1], act_, slope_, dt)
+            ops.wgrad(wg, xin, dY, gw, acc, dt, alg=st.alg(B, dt))
         if st.has_bias:
             gb, accb = sink.get(st.conv.bias)
             ops.bias_grad(dY, rows, OC, st.cout, gb, accb, dt)

@@ -332,8 +332,11 @@ def gather_gemm(g: GGSpec, X: torch.Tensor, Wp: torch.Tensor, dtype: int, bias: 
     return Y, stats, nparts
 
 
-def edge_wgrad(ew: EWSpec, wide: torch.Tensor, narrow: torch.Tensor, dW: torch.Tensor, accumulate: bool, alg=None) -> None:
-    """Weight gradient of an edge layer (vg_edge_wgrad): wide [B,WH,WW,C] bf16, narrow [B,NH,NW,8] bf16, dW f32."""
+def edge_wgrad(ew: EWSpec, wide: torch.Tensor, narrow: torch.Tensor, dW: torch.Tensor, accumulate: bool, alg=None,
+               pre=None) -> None:
+    """Weight gradient of an edge layer (vg_edge_wgrad): wide [B,WH,WW,C] bf16, narrow [B,NH,NW,8] bf16, dW f32.
+    pre = (scale [C], shift [C], act, slope): `wide` is the RAW output of the layer below; its BatchNorm + activation
+    are applied inside the kernel."""
     _need_cuda(wide, narrow, dW)
     if wide.dtype != torch.bfloat16 or narrow.dtype != torch.bfloat16 or dW.dtype != torch.float32:
         raise RuntimeError("edge_wgrad: bf16 operands, float32 gradient")
@@ -343,6 +346,8 @@ def edge_wgrad(ew: EWSpec, wide: torch.Tensor, narrow: torch.Tensor, dW: torch.T
     d = L.EWDesc(Wd=wide.data_ptr(), Nr=narrow.data_ptr(), dW=dW.data_ptr(), ws=0, ws_bytes=0,
                  zeros=zero_page(wide.device).data_ptr(), B=ew.B, WH=ew.WH, WW=ew.WW, C=ew.C, NH=ew.NH, NW=ew.NW, N=ew.N,
                  K=ew.K, S=ew.S, P=ew.P, s_c=ew.s_c, s_n=ew.s_n, accumulate=1 if accumulate else 0)
+    if pre is not None:
+        d.in_scale, d.in_shift, d.in_act, d.in_slope = pre[0].data_ptr(), pre[1].data_ptr(), pre[2], pre[3]
     nbytes = lib.vg_edge_wgrad_ws_bytes(byref(d))
     if nbytes < 0:
         L.check(int(nbytes), "vg_edge_wgrad_ws_bytes")
@@ -365,9 +370,11 @@ def cast_fp8(x: torch.Tensor, shift: int = 0, out: torch.Tensor = None) -> torch
 
 
 def tnconv(tn: TNSpec, X: torch.Tensor, Wp: torch.Tensor, want_nhwc: bool = True, want_nchw: bool = False,
-           act: int = 0, noise=None, sigma: float = 0.0, out_nhwc: torch.Tensor = None, alg=None):
+           act: int = 0, noise=None, sigma: float = 0.0, out_nhwc: torch.Tensor = None, alg=None, pre=None):
     """Narrow-N transposed convolution (vg_tnconv) -> (Y NHWC bf16 [B,OH,OW,OC] or None, Y NCHW f32 or None).
-    noise: None, an NCHW f32 tensor [B,N,OH,OW] or a NoiseDraw; with noise, Y = act(.) + sigma*noise."""
+    noise: None, an NCHW f32 tensor [B,N,OH,OW] or a NoiseDraw; with noise, Y = act(.) + sigma*noise.
+    pre = (scale [C], shift [C], act, slope): X is the RAW output of the layer below; its BatchNorm + activation are
+    applied inside the kernel (no separate vg_bn_act_forward pass, no activated copy of X)."""
     rng = isinstance(noise, NoiseDraw)
     _need_cuda(X, Wp, None if rng else noise, out_nhwc)
     if X.dtype != torch.bfloat16 or Wp.dtype != torch.bfloat16:
@@ -388,6 +395,8 @@ def tnconv(tn: TNSpec, X: torch.Tensor, Wp: torch.Tensor, want_nhwc: bool = True
                  rng=noise.state.data_ptr() if rng else 0, draw=noise.draw if rng else 0, sigma=sigma,
                  B=tn.B, IH=tn.IH, IW=tn.IW, C=tn.C, N=tn.N, K=tn.K, S=tn.S, P=tn.P, OH=tn.OH, OW=tn.OW, OC=tn.OC,
                  Wpitch=tn.Wpitch, act=act)
+    if pre is not None:
+        d.in_scale, d.in_shift, d.in_act, d.in_slope = pre[0].data_ptr(), pre[1].data_ptr(), pre[2], pre[3]
     tok = TIMER.begin("edge", *(alg or (tn.flops(), 0))) if TIMER is not None else None
     L.check(L.load().vg_tnconv(byref(d), L.stream_ptr()), "vg_tnconv")
     if tok is not None:
