@@ -728,6 +728,86 @@ def test_bn_backward_finalize_and_apply_in_one_launch(ops, monkeypatch, rpg, C, 
     torch.testing.assert_close(out["1"][0][:rpg].double().cpu(), dx_ref.view(rpg, C), rtol=5e-2, atol=5e-2)
 
 
+BNB_CASES = [  # kind, B, H, Cin, Cout, act, slope: data-gradient launches whose output lands under a BatchNorm layer
+    ("convT_dgrad", 8, 16, 128, 128, 1, 0.0), ("convT_dgrad", 16, 4, 256, 512, 1, 0.0), ("convT_dgrad", 4, 8, 160, 64, 1, 0.0),
+    ("conv_dgrad", 8, 32, 128, 256, 2, 0.2), ("conv_dgrad", 8, 32, 64, 128, 2, 0.2), ("conv_dgrad", 4, 64, 32, 64, 2, 0.2),
+    ("convT3_dgrad", 4, 32, 64, 3, 1, 0.0), ("convT3_dgrad", 2, 64, 32, 3, 1, 0.0),          # narrow-K kernel (G5's dgrad)
+]
+
+
+@pytest.mark.parametrize("kind,B,H,Cin,Cout,act,slope", BNB_CASES)
+def test_data_gradient_epilogue_emits_the_batchnorm_backward_sums(ops, monkeypatch, kind, B, H, Cin, Cout, act, slope):
+    """vg_gg_desc.bnb_*: the slabs a data-gradient launch writes, summed over their rows, against the column sums
+    vg_bn_act_backward_reduce produces from the same (stored, rounded) gradient; the gradient itself is untouched; and
+    ops.bn_act_backward(partial=...) gives the dx / dgamma / dbeta of the three-pass form."""
+    dt = G.BF16
+    g = torch.Generator().manual_seed(H * 5 + Cin)
+    if kind == "conv_dgrad":
+        dy = _q(torch.randn(B, Cout, H // 2, H // 2, generator=g), dt)
+        w = torch.randn(Cout, Cin, 4, 4, generator=g) * 0.1
+        gg, pk = G.conv_dgrad(B, H, H, Cin, Cout, 4, 2, 1, dt)
+    elif kind == "convT_dgrad":
+        dy = _q(torch.randn(B, Cout, 2 * H, 2 * H, generator=g), dt)
+        w = torch.randn(Cin, Cout, 4, 4, generator=g) * 0.1
+        gg, pk = G.convT_dgrad(B, H, H, Cin, Cout, 4, 2, 1, dt)
+    else:                                            # ConvTranspose2d(Cin -> 3, k3 s1 p1): the Generator's last layer
+        dy = _q(torch.randn(B, Cout, H, H, generator=g), dt)
+        w = torch.randn(Cin, Cout, 3, 3, generator=g) * 0.1
+        gg, pk = G.convT_dgrad(B, H, H, Cin, Cout, 3, 1, 1, dt)
+    Wp = ops.pack_weights(pk, w.to(DEV), dt)
+    X = _dev(to_nhwc(dy, gg.IC), dt, ops)
+    monkeypatch.setenv("VG_TILE_MIN_WGS", "1")
+    monkeypatch.setenv("VG_SPLITK_MAX_TILES", "0")   # (split-K, which these small problems would take, has no epilogue)
+    nparts = ops.gather_gemm_bnb_parts(gg, X, Wp, dt)
+    assert nparts > 0, "this shape is expected on a kernel with the epilogue"
+    rows, C = B * H * H, Cin
+    y = (torch.randn(rows, C, generator=g) * 1.3 + 0.2).to(DEV).to(torch.bfloat16)          # raw output of the layer below
+    gamma = (torch.randn(C, generator=g) * 0.1 + 1).to(DEV)
+    beta = (torch.randn(C, generator=g) * 0.1).to(DEV)
+    mean, var = y.float().mean(0), y.float().var(0, unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    scale = gamma * invstd
+    co = torch.stack([mean, invstd, scale, beta - mean * scale]).unsqueeze(0).contiguous()
+    D0, _, _ = ops.gather_gemm(gg, X, Wp, dt)
+    D0 = D0.clone()
+    D1, slab, n = ops.gather_gemm(gg, X, Wp, dt, bnb=(y.view(D0.shape), co[0], act, slope))
+    assert n == nparts and torch.equal(D0, D1)
+    got = slab[: n * 2 * C].view(n, 2, C).double().sum(0).cpu()
+    # the reduce pass on the same stored gradient
+    yf, df = y.double().cpu(), D1.reshape(rows, C).double().cpu()
+    z = scale.double().cpu() * yf + (beta - mean * scale).double().cpu()
+    dz = df * torch.where(z > 0, torch.ones_like(z), torch.full_like(z, slope if act == 2 else 0.0))
+    xhat = (yf - mean.double().cpu()) * invstd.double().cpu()
+    want = torch.stack([dz.sum(0), (dz * xhat).sum(0)])
+    tol = 2e-5 * torch.stack([dz.abs().sum(0), (dz * xhat).abs().sum(0)]) + 1e-6
+    assert bool(((got - want).abs() <= tol).all()), float(((got - want).abs() / tol).max())
+    # and through the BatchNorm backward
+    out = {}
+    for mode in ("three", "partial"):
+        dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        if mode == "partial":
+            _, slab, n = ops.gather_gemm(gg, X, Wp, dt, bnb=(y.view(D0.shape), co[0], act, slope))
+        dx = ops.bn_act_backward(y, D1.reshape(rows, C), co, rows, C, rows, gamma, act, slope, dg, db, False, dt,
+                                 partial=(slab, n) if mode == "partial" else None)
+        out[mode] = (dx.clone(), dg, db)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(out["partial"][1], out["three"][1], rtol=2e-5, atol=2e-4 * float(out["three"][1].abs().max()))
+    torch.testing.assert_close(out["partial"][2], out["three"][2], rtol=2e-5, atol=2e-4 * float(out["three"][2].abs().max()))
+    d = (out["partial"][0].float() - out["three"][0].float()).abs()
+    assert float(d.max()) <= 2.0 ** -7 * float(out["three"][0].float().abs().max()) and float((d > 0).float().mean()) < 1e-3
+
+
+def test_batchnorm_backward_epilogue_is_refused_where_no_kernel_has_it(ops):
+    """A descriptor on a kernel without the epilogue (f32) probes 0 and the launch is refused rather than silently skipped."""
+    gg, pk = G.convT_dgrad(4, 8, 8, 64, 64, 4, 2, 1, G.F32)
+    X = torch.zeros(4, 16, 16, gg.IC, device=DEV)
+    w = torch.zeros(64, 64, 4, 4, device=DEV)
+    Wp = ops.pack_weights(pk, w, G.F32)
+    assert ops.gather_gemm_bnb_parts(gg, X, Wp, G.F32) == 0
+    with pytest.raises(RuntimeError):
+        ops.gather_gemm(gg, X, Wp, G.F32, bnb=(torch.zeros(4, 8, 8, 64, device=DEV), torch.zeros(4, 64, device=DEV), 1, 0.0))
+
+
 def test_edge_kernels_apply_the_batchnorm_of_the_layer_below_on_their_loads(ops):
     """vg_tnconv / vg_edge_wgrad input prologue: fed the RAW output of the layer below plus its BatchNorm scale / shift
     and activation, they must give bit for bit what they give on the tensor vg_bn_act_forward stores."""

@@ -867,3 +867,24 @@ def test_edge_prologue_training_iteration_equals_default(monkeypatch):
         torch.cuda.synchronize()
         outs.append(torch.stack([l1, l2]).cpu())
     assert torch.equal(outs[0], outs[1])
+
+
+def test_batchnorm_backward_sums_in_the_data_gradient_epilogue_train_like_the_default(monkeypatch):
+    """VG_BNB=1 (stage i+1's data-gradient launch emits the BatchNorm-backward partial sums of stage i; no reduce pass):
+    the sums are the same numbers added in another order, so two bf16 training iterations agree to f32 rounding of the
+    BatchNorm parameter gradients -- losses after one step identical to 5e-3 relative."""
+    outs, kernels = [], []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("VG_BNB", mode)
+        V.configure_seed(42)
+        e, g, d, tr = build(64, dtype="bf16")
+        assert g._engine.bnb_epilogue == (mode == "1")
+        x = torch.randn(8, 3, 64, 64, generator=torch.Generator().manual_seed(3)).clamp(-1, 1).to(DEV)
+        l1 = tr.train_step(x, 60)[:5].clone()
+        l2 = tr.train_step(x, 60)[:5].clone()
+        torch.cuda.synchronize()
+        outs.append(torch.stack([l1, l2]).cpu())
+        kernels.append(sum(p.detach().double().sum().item() for p in g.parameters()))
+    assert torch.equal(outs[0][0], outs[1][0])                       # the first iteration's losses precede any update
+    torch.testing.assert_close(outs[1][1], outs[0][1], rtol=5e-3, atol=1e-3)
+    assert abs(kernels[0] - kernels[1]) <= 1e-3 * abs(kernels[0]) + 1e-3

@@ -16,7 +16,7 @@ VG_F32, VG_BF16, VG_FP8 = 0, 1, 2
 VG_FP8_WSHIFT = 6
 VG_ACT_NONE, VG_ACT_RELU, VG_ACT_LRELU, VG_ACT_TANH = 0, 1, 2, 3
 VG_MAX_PHASE = 4
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _ERR = {-1: "VG_EINVAL (bad shape/size/flag)", -2: "VG_EALIGN (16-byte contract violated)",
         -3: "VG_ENOSUP (unsupported configuration)"}
@@ -36,7 +36,9 @@ class GGDesc(Structure):
                 ("ooy", _I4), ("oox", _I4),
                 ("nphase", c_int32), ("stats_capacity", c_int32), ("ws", c_void_p), ("ws_bytes", c_int64), ("zeros", c_void_p),
                 ("act", c_int32), ("act_slope", c_float),
-                ("mask_x", c_void_p), ("mask_act", c_int32), ("mask_slope", c_float)]
+                ("mask_x", c_void_p), ("mask_act", c_int32), ("mask_slope", c_float),
+                ("bnb_y", c_void_p), ("bnb_coeffs", c_void_p), ("bnb_partial", c_void_p), ("bnb_act", c_int32),
+                ("bnb_slope", c_float), ("bnb_capacity", c_int32)]
 
 
 class WGDesc(Structure):
@@ -87,6 +89,7 @@ SIGNATURES = {
     "vg_timing_enable": (c_int, [_I]),
     "vg_timing_collect": (c_int, [_I, POINTER(c_double), POINTER(c_int)]),
     "vg_gather_gemm_nparts": (c_int, [POINTER(GGDesc), _I]),
+    "vg_gather_gemm_bnb_nparts": (c_int, [POINTER(GGDesc), _I]),
     "vg_gather_gemm_tile_m": (c_int, [POINTER(GGDesc), _I]),
     "vg_gather_gemm_family": (c_int, [POINTER(GGDesc), _I]),
     "vg_gather_gemm_ws_bytes": (c_int64, [POINTER(GGDesc), _I]),

@@ -857,6 +857,30 @@ extern "C" int vg_gather_gemm_nparts(const vg_gg_desc* d, int dtype) {
     return d->nphase * ((M + t.bm - 1) / t.bm);
 }
 
+namespace {
+// rows of bnb_partial a launch writes (0: the kernel this descriptor runs on has no BatchNorm-backward epilogue)
+inline int bnb_parts(const vg_gg_desc* d, int dtype) {
+    if (dtype != VG_BF16) return 0;
+    PatchGeo pg;
+    StatPlan sp;
+    if (stationary_plan(d, dtype, &pg, &sp)) return 0;
+    const int M = d->B * d->GH * d->GW;
+    if (narrowk_ok(d, dtype)) return (64 % (d->N * 2 / 16) == 0) ? (M + NK_BM - 1) / NK_BM : 0;
+    const TileCfg t = pick_tile(d, true, false);
+    const SplitK sk = plan_splitk(d, dtype, t);
+    if ((t.bm == 128 || t.bm == 256) && (t.bn == GP_BN || (t.bn == 64 && patch64()) || (t.bn == 32 && d->N == 32 && patch32())) &&
+        sk.ksplit <= 1 && use_patch() && use_dma() && d->zeros != nullptr && patch_geometry(d, t.bm, &pg))
+        return d->nphase * (M / t.bm);
+    return 0;
+}
+}  // namespace
+
+extern "C" int vg_gather_gemm_bnb_nparts(const vg_gg_desc* d, int dtype) {
+    int rc = validate(d, dtype);
+    if (rc) return rc;
+    return bnb_parts(d, dtype);
+}
+
 extern "C" int vg_gather_gemm_family(const vg_gg_desc* d, int dtype) {
     int rc = validate(d, dtype);
     if (rc) return rc;
@@ -881,6 +905,12 @@ extern "C" int64_t vg_gather_gemm_ws_bytes(const vg_gg_desc* d, int dtype) {
 extern "C" int vg_gather_gemm(const vg_gg_desc* d, int dtype, void* stream) {
     int rc = validate(d, dtype);
     if (rc) return rc;
+    if (d->bnb_y != nullptr) {                                  // BatchNorm-backward sums in the epilogue: probe first
+        VG_CHECK_ARG(d->bnb_coeffs && d->bnb_partial && vg_aligned16(d->bnb_y) && d->mask_x == nullptr && d->stats == nullptr, VG_EINVAL);
+        const int np = bnb_parts(d, dtype);
+        if (np <= 0) return VG_ENOSUP;
+        VG_CHECK_ARG(d->bnb_capacity >= np, VG_EINVAL);
+    }
     PatchGeo pg;
     StatPlan sp;
     if (stationary_plan(d, dtype, &pg, &sp)) {                  // short-K transposed forms: weights resident in LDS

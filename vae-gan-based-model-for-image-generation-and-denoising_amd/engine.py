@@ -157,6 +157,11 @@ class StackEngine:
         # gradient and joined before the NEXT data gradient, so it runs beside the BatchNorm-backward chain of stage
         # i-1 only and two GEMM-class grids never share the chip.
         self.wgrad_under_bn = os.environ.get("VG_SIDE_WGRAD", "0") == "2"
+        # VG_BNB=1: BatchNorm-backward sums of stage i-1 in the epilogue of stage i's data-gradient GEMM (no reduce pass:
+        # 7 launches fewer per iteration).  MEASURED NEUTRAL (2.816 / 2.820 vs 2.821 / 2.810 ms, tools/ab_bnb.sh): the
+        # reduce passes go (-67 us) but the GEMM epilogues that now read the raw output grow by as much (+62 us,
+        # tools/ab_bnb_trace.sh) -- the bytes are the same HBM bytes either way.  Opt-in.
+        self.bnb_epilogue = os.environ.get("VG_BNB", "0") == "1"
 
     # ---- geometry (cached per batch size) -----------------------------------------------------
     def spec(self, i: int, B: int, what: str):
@@ -499,6 +504,7 @@ class StackEngine:
         forked = None                       # stage whose parameter gradients are in flight on the fork/join stream
         held = []                           # tensors the side stream reads: kept alive until the join
         masked = False                      # dA already carries the activation backward of the stage it belongs to
+        bn_partial = None                   # (slabs, n): BatchNorm-backward sums of stage i, emitted by stage i+1's dgrad
 
         def join_forked():
             nonlocal forked
@@ -533,7 +539,8 @@ class StackEngine:
                 else:
                     gg_, gb_, acc_g = None, None, False
                 dY = ops.bn_act_backward(Y, dA, c["coeffs"], rows, OC, rows, st.bn.weight.detach(), st.act, st.slope,
-                                         gg_, gb_, acc_g, dt, sync=self.bn_sync)
+                                         gg_, gb_, acc_g, dt, sync=self.bn_sync, partial=bn_partial)
+                bn_partial = None
             elif st.act != VG_ACT_NONE and not masked:
                 dY = ops.act_backward(Y, dA, st.act, st.slope, dt)
             else:
@@ -570,7 +577,18 @@ class StackEngine:
                             ggd.OC == pc["OC"]:
                         mask = (pc["Y"], pst.act, pst.slope)
                         masked = True
-                dX, _, _ = ops.gather_gemm(ggd, dY, packs[i]["dgrad"], dt, alg=st.alg(B, dt), mask=mask)
+                bnb = None
+                if i > 0 and self.bnb_epilogue and self.bn_sync is None:
+                    pst, pc = self.stages[i - 1], ctx[i - 1]
+                    # the stage below has BatchNorm: this launch's epilogue also sums dz and dz*xhat over its tile, which
+                    # is the whole reduce pass of that BatchNorm's backward (ops.gather_gemm bnb=)
+                    if pst.bn is not None and pc.get("Y") is not None and pc["coeffs"].shape[0] == 1 and \
+                            ggd.N == pc["OC"] and pc["coeffs"].shape[-1] == ggd.N and \
+                            ops.gather_gemm_bnb_parts(ggd, dY, packs[i]["dgrad"], dt) > 0:
+                        bnb = (pc["Y"], pc["coeffs"][0], pst.act, pst.slope)
+                dX, slab, nslab = ops.gather_gemm(ggd, dY, packs[i]["dgrad"], dt, alg=st.alg(B, dt), mask=mask, bnb=bnb)
+                if bnb is not None:
+                    bn_partial = (slab, nslab)
                 dA = dX.view(c["x"].shape)
             else:
                 dA = None

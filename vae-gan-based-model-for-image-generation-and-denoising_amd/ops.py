@@ -282,9 +282,25 @@ def _gg_desc(g: GGSpec, X, Wp, Y, bias, stats, cap) -> L.GGDesc:
                     OSY=g.OSY, OSX=g.OSX, ooy=L.i4(g.ooy), oox=L.i4(g.oox), nphase=g.nphase, stats_capacity=cap)
 
 
+def gather_gemm_bnb_parts(g: GGSpec, X: torch.Tensor, Wp: torch.Tensor, dtype: int) -> int:
+    """> 0 (the number of partial rows) when the launch of this descriptor can emit the BatchNorm-backward sums of the layer
+    below in its epilogue (gather_gemm(..., bnb=...)), else 0."""
+    if dtype != BF16:
+        return 0
+    probe = _gg_desc(g, X, Wp, X, None, None, 0)
+    r = L.load().vg_gather_gemm_bnb_nparts(byref(probe), dtype)
+    if r < 0:
+        L.check(r, "vg_gather_gemm_bnb_nparts")
+    return r
+
+
 def gather_gemm(g: GGSpec, X: torch.Tensor, Wp: torch.Tensor, dtype: int, bias: torch.Tensor = None,
-                want_stats: bool = False, out: torch.Tensor = None, alg=None, act=None, mask=None):
-    """Returns (Y [B,OH,OW,OC], stats slabs or None, nparts).  alg = (flops, bytes) of the layer for the timer."""
+                want_stats: bool = False, out: torch.Tensor = None, alg=None, act=None, mask=None, bnb=None):
+    """Returns (Y [B,OH,OW,OC], stats slabs or None, nparts).  alg = (flops, bytes) of the layer for the timer.
+    bnb = (y, coeffs [4][N] f32, act, slope) on a data-gradient launch whose output is the gradient w.r.t. the activated
+    output of a BatchNorm layer (y: that layer's raw conv output, Y-shaped): the epilogue also emits the backward partial
+    sums (sum dz | sum dz*xhat) -- returned in place of the stats slabs, with their row count -- so that
+    bn_act_backward(partial=...) needs no reduce pass.  Only where gather_gemm_bnb_parts() > 0."""
     _need_cuda(X, Wp, bias, out)
     if X.dtype != TORCH_DT[dtype] or Wp.dtype != TORCH_DT[dtype]:
         raise RuntimeError(f"gather_gemm: operand dtype {X.dtype}/{Wp.dtype} does not match engine dtype")
@@ -312,6 +328,16 @@ def gather_gemm(g: GGSpec, X: torch.Tensor, Wp: torch.Tensor, dtype: int, bias: 
         if mx.numel() != Y.numel() or mx.dtype != Y.dtype:
             raise RuntimeError("gather_gemm: mask tensor must be shaped and typed like the output")
         d.mask_x, d.mask_act, d.mask_slope = mx.data_ptr(), mact, mslope
+    if bnb is not None:
+        by, bco, bact, bslope = bnb
+        if want_stats or mask is not None or by.numel() != Y.numel() or by.dtype != Y.dtype or bco.numel() != 4 * g.N:
+            raise RuntimeError("gather_gemm: bnb needs a Y-shaped raw tensor, [4][N] coefficients, no stats / mask")
+        nparts = gather_gemm_bnb_parts(g, X, Wp, dtype)
+        if nparts <= 0:
+            raise RuntimeError("gather_gemm: this launch has no BatchNorm-backward epilogue (probe gather_gemm_bnb_parts)")
+        stats = WS.get("bnbwd", max(nparts, 2048) * 2 * g.N * 4, X.device)
+        d.bnb_y, d.bnb_coeffs, d.bnb_partial = by.data_ptr(), bco.data_ptr(), stats.data_ptr()
+        d.bnb_act, d.bnb_slope, d.bnb_capacity = bact, bslope, max(nparts, 2048)
     wsb = lib.vg_gather_gemm_ws_bytes(byref(d), dtype)
     ws = None
     if wsb > 0:
@@ -321,7 +347,7 @@ def gather_gemm(g: GGSpec, X: torch.Tensor, Wp: torch.Tensor, dtype: int, bias: 
     if TIMER is not None:
         fam = {0: "gather_gemm", 2: "edge", 3: "gather_gemm_fp8"}[lib.vg_gather_gemm_family(byref(d), dtype)]
         tok = TIMER.begin(fam, *(alg or (g.flops(), 0)))
-    if BINDING == "torchops":
+    if BINDING == "torchops" and bnb is None:      # (the custom-op face has no bnb arguments: that launch goes through ctypes)
         torch_ops().gather_gemm(X, Wp, Y, bias, stats, ws if wsb > 0 else None, zero_page(X.device),
                                 mask[0] if mask is not None else None, _gg_geom(d), float(d.act_slope),
                                 float(d.mask_slope), dtype)
@@ -527,18 +553,27 @@ def channel_stats(x, rows, C, dtype):
     return stats, n.value
 
 
-def bn_act_backward(x, dy, coeffs, rows, C, count, gamma, act, slope, dgamma, dbeta, accumulate, dtype, sync=None):
-    """Full BN(+act) backward: returns dx (gradient w.r.t. the raw conv output).  coeffs: [groups][4][C]."""
+def bn_act_backward(x, dy, coeffs, rows, C, count, gamma, act, slope, dgamma, dbeta, accumulate, dtype, sync=None,
+                    partial=None):
+    """Full BN(+act) backward: returns dx (gradient w.r.t. the raw conv output).  coeffs: [groups][4][C].
+    partial = (slabs [n][2][C], n): the (sum dz | sum dz*xhat) partials already produced by the data-gradient kernel that
+    wrote dy (gather_gemm(..., bnb=...)); the reduce pass is skipped (groups == 1, no sync)."""
     _need_cuda(x, dy, coeffs)
     lib = L.load()
     groups = coeffs.shape[0]
     n = c_int(0)
     cap = 2048
-    partial = WS.get("bnbwd", cap * 2 * C * 4, x.device)
-    L.check(lib.vg_bn_act_backward_reduce(x.data_ptr(), dy.data_ptr(), coeffs[0, 2].data_ptr(),
-                                          coeffs[0, 3].data_ptr(), coeffs[0, 0].data_ptr(), coeffs[0, 1].data_ptr(),
-                                          rows, C, act, slope, partial.data_ptr(), cap, byref(n), groups, 4 * C, dtype,
-                                          L.stream_ptr()), "vg_bn_act_backward_reduce")
+    if partial is not None:
+        if groups != 1 or sync is not None:
+            raise RuntimeError("bn_act_backward: precomputed partials need groups == 1 and no SyncBN")
+        partial, nn = partial
+        n = c_int(nn)
+    else:
+        partial = WS.get("bnbwd", cap * 2 * C * 4, x.device)
+        L.check(lib.vg_bn_act_backward_reduce(x.data_ptr(), dy.data_ptr(), coeffs[0, 2].data_ptr(),
+                                              coeffs[0, 3].data_ptr(), coeffs[0, 0].data_ptr(), coeffs[0, 1].data_ptr(),
+                                              rows, C, act, slope, partial.data_ptr(), cap, byref(n), groups, 4 * C,
+                                              dtype, L.stream_ptr()), "vg_bn_act_backward_reduce")
     if sync is None and x.shape[-1] == C and \
             lib.vg_bn_finalize_act_forward_supported(n.value, groups, C, rows, dtype):
         # small layer: finalize + apply in one launch (bn_act.hip bn_bwd_fin_apply_kernel); n = partial rows PER GROUP
