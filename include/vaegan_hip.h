@@ -48,9 +48,10 @@ extern "C" {
 #define VG_ACT_LRELU   2   /* nn.LeakyReLU(slope)    main_vae.py:25, gan_code.py:62-82 */
 #define VG_ACT_TANH    3   /* nn.Tanh()              gan_code.py:50 (vg_tnconv epilogue only) */
 
-#define VG_ABI_VERSION 6   /* 2: vg_pack_desc.tile_start, SyncBN / WGAN / data-path entry points; 3: in-kernel noise (vg_*_rng);
+#define VG_ABI_VERSION 7   /* 2: vg_pack_desc.tile_start, SyncBN / WGAN / data-path entry points; 3: in-kernel noise (vg_*_rng);
                              4: vg_bn_finalize_act_forward, vg_bn_backward_finalize_apply;
-                             5: input prologue of vg_tn_desc / vg_ew_desc; 6: vg_gg_desc.bnb_* */
+                             5: input prologue of vg_tn_desc / vg_ew_desc; 6: vg_gg_desc.bnb_*;
+                             7: vg_bce_pair_forward_backward */
 int vg_abi_version(void);
 /* Live kernel timing for the roofline report: while enabled, gather-GEMM (family 0) and wgrad (family 1)
  * launches carry a HIP start/stop event pair on their stream (hipExtLaunchKernelGGL); collect() synchronises,
@@ -392,6 +393,11 @@ int vg_dot_wgrad(const void* x, const float* dlogit, float* dw, int B, int K, in
  * loss[0] (+)= value when accumulate; dp[b] = gscale*(p-t)/max(p*(1-p),1e-12)/B (dp NULL ok). */
 int vg_bce_forward_backward(const float* p, float target, int B, float gscale,
                             float* loss, int accumulate, float* dp, void* stream);
+/* The Discriminator loss of one update, both halves in one launch (vaegan_code.py:98-103; ABI 7): p = [B real | B fake],
+ * loss[0] (+)= BCE(p[:B], target0) + BCE(p[B:], target1), dp likewise [2B] -- bit-identical to two vg_bce_forward_backward
+ * calls, the second accumulating. */
+int vg_bce_pair_forward_backward(const float* p, float target0, float target1, int B, float gscale,
+                                 float* loss, int accumulate, float* dp, void* stream);
 /* Sibling loop train_wgan (gan_code.py:306-315, :328): loss[0] (+)= sign*mean_b p[b]; dp[b] = sign*gscale/B. */
 int vg_mean_forward_backward(const float* p, float sign, int B, float gscale,
                              float* loss, int accumulate, float* dp, void* stream);

@@ -847,3 +847,19 @@ def test_edge_kernels_apply_the_batchnorm_of_the_layer_below_on_their_loads(ops)
     ops.edge_wgrad(ew2, a2, dimg, e1, False)
     ops.edge_wgrad(ew2, y2, dimg, e2, False, pre=(sc2, sh2, 2, 0.2))
     assert torch.equal(e1, e2)
+
+
+@pytest.mark.parametrize("B", [1, 37, 128, 300])
+def test_pair_bce_is_two_bce_launches_bit_for_bit(ops, B):
+    """vg_bce_pair_forward_backward (the grouped Discriminator pass) against two vg_bce_forward_backward launches, the
+    second accumulating: same loss bits, same gradient bits."""
+    g = torch.Generator().manual_seed(B)
+    p = torch.rand(2 * B, generator=g).clamp(1e-4, 1 - 1e-4).to(DEV)
+    p[0] = 0.0                                        # log clamp
+    l1, l2 = torch.zeros(1, device=DEV), torch.full((1,), 7.0, device=DEV)
+    d1, d2 = torch.empty_like(p), torch.empty_like(p)
+    ops.bce_forward_backward(p[:B], 1.0, 0.5, l1, False, True, out=d1[:B])
+    ops.bce_forward_backward(p[B:], 0.0, 0.5, l1, True, True, out=d1[B:])
+    ops.bce_pair_forward_backward(p, 1.0, 0.0, 0.5, l2, d2)
+    torch.cuda.synchronize()
+    assert torch.equal(l1, l2) and torch.equal(d1, d2)

@@ -16,7 +16,7 @@ VG_F32, VG_BF16, VG_FP8 = 0, 1, 2
 VG_FP8_WSHIFT = 6
 VG_ACT_NONE, VG_ACT_RELU, VG_ACT_LRELU, VG_ACT_TANH = 0, 1, 2, 3
 VG_MAX_PHASE = 4
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _ERR = {-1: "VG_EINVAL (bad shape/size/flag)", -2: "VG_EALIGN (16-byte contract violated)",
         -3: "VG_ENOSUP (unsupported configuration)"}
@@ -132,6 +132,7 @@ SIGNATURES = {
     "vg_dot_sigmoid_backward": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "vg_dot_wgrad": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "vg_bce_forward_backward": (c_int, [_P, _F, _I, _F, _P, _I, _P, _P]),
+    "vg_bce_pair_forward_backward": (c_int, [_P, _F, _F, _I, _F, _P, _I, _P, _P]),
     "vg_mean_forward_backward": (c_int, [_P, _F, _I, _F, _P, _I, _P, _P]),
     "vg_clamp": (c_int, [_P, _L, _F, _F, _P]),
     "vg_mse_forward_backward": (c_int, [_P, _P, _L, _F, _P, _P, _P, _I, _P]),

@@ -359,15 +359,20 @@ __global__ __launch_bounds__(256) void edge_wgrad_kernel(const vg_ew_desc d, con
     }
 }
 
-// Two-level fixed-order sum of the workgroups' partials (a one-level loop over ~500 partials is a chain of dependent
-// HBM round trips: it cost more than the kernel it finishes).  Level 1: block (chunk of 256 outputs, group of parts)
-// sums its <= nparts/EW_G partials, 8 loads in flight per thread, whole 1-KiB rows per wave.  Level 2: EW_G partials per
-// output, scatter into dW[c*s_c + n*s_n + tap].
+// Fixed-order sum of the workgroups' partials in ONE launch (a one-level loop over ~500 partials per thread is a chain of
+// dependent HBM round trips: it cost more than the kernel it finishes; two launches -- groups of parts, then groups --
+// cost two launch floors, 8.3 us per layer).  A 16-wave workgroup owns 64 consecutive outputs: wave g sums parts
+// [g*per, (g+1)*per) for them, 8 loads in flight per lane, one 256-byte run per part row; the EW_G wave sums are added in
+// wave order through LDS and scattered into dW[c*s_c + n*s_n + tap].  (Same grouping, same order, same bits as the
+// two-launch form it replaces.)
 constexpr int EW_G = 16;
 
-__global__ __launch_bounds__(256) void edge_wgrad_reduce1_kernel(const float* __restrict__ ws, float* __restrict__ ws2,
-                                                                 int nparts, int JC) {
-    const int idx = blockIdx.x * 256 + threadIdx.x, grp = blockIdx.y;
+__global__ __launch_bounds__(64 * EW_G) void edge_wgrad_reduce_kernel(const vg_ew_desc d, const float* __restrict__ ws,
+                                                                      int nparts, int J, int C) {
+    __shared__ float red[EW_G][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + lane;                       // = j * C + c  (J * C is a multiple of 64)
+    const int JC = J * C;
     const int per = (nparts + EW_G - 1) / EW_G;
     const int k0 = grp * per, k1 = min(nparts, k0 + per);
     float s = 0.f;
@@ -380,23 +385,17 @@ __global__ __launch_bounds__(256) void edge_wgrad_reduce1_kernel(const float* __
         for (int u = 0; u < 8; ++u) s += v[u];
     }
     for (; k < k1; ++k) s += ws[(int64_t)k * JC + idx];
-    ws2[(int64_t)grp * JC + idx] = s;
-}
-
-__global__ __launch_bounds__(256) void edge_wgrad_reduce2_kernel(const vg_ew_desc d, const float* __restrict__ ws2, int J, int C) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;               // = j * C + c
-    if (idx >= J * C) return;
+    red[grp][lane] = s;
+    __syncthreads();
+    if (grp != 0) return;
     const int j = idx / C, c = idx - j * C;
     const int n = j & 3, tap = j >> 2;
     if (n >= d.N || tap >= d.K * d.K) return;
-    float v[EW_G];
+    float t = 0.f;
 #pragma unroll
-    for (int g = 0; g < EW_G; ++g) v[g] = ws2[(int64_t)g * J * C + idx];
-    float s = 0.f;
-#pragma unroll
-    for (int g = 0; g < EW_G; ++g) s += v[g];
+    for (int g = 0; g < EW_G; ++g) t += red[g][lane];
     float* dst = d.dW + (int64_t)c * d.s_c + (int64_t)n * d.s_n + tap;
-    *dst = d.accumulate ? *dst + s : s;
+    *dst = d.accumulate ? *dst + t : t;
 }
 
 struct EwPlan { int R, tiles_per_img, ntiles, JT, CT, grid; int64_t ws_bytes; };
@@ -418,7 +417,7 @@ inline int ew_plan(const vg_ew_desc* d, EwPlan* p) {
     p->tiles_per_img = (d->WH + R - 1) / R;
     p->ntiles = d->B * p->tiles_per_img;
     p->grid = p->ntiles < 512 ? p->ntiles : 512;                   // 2 workgroups per CU, each walks several tiles
-    p->ws_bytes = (int64_t)(p->grid + EW_G) * p->JT * 16 * d->C * 4;   // partials + the level-1 sums
+    p->ws_bytes = (int64_t)p->grid * p->JT * 16 * d->C * 4;          // one [J][C] partial per workgroup
     return 0;
 }
 
@@ -463,8 +462,6 @@ extern "C" int vg_edge_wgrad(const vg_ew_desc* d, void* stream) {
     rc = VG_LAUNCH_RC();
     if (rc) return rc;
     const int JC = p.JT * 16 * d->C;                                // multiple of 256 (C >= 32, J >= 48)
-    float* ws2 = d->ws + (int64_t)p.grid * JC;
-    hipLaunchKernelGGL(edge_wgrad_reduce1_kernel, dim3(JC / 256, EW_G), dim3(256), 0, s, d->ws, ws2, p.grid, JC);
-    hipLaunchKernelGGL(edge_wgrad_reduce2_kernel, dim3(JC / 256), dim3(256), 0, s, *d, ws2, p.JT * 16, d->C);
+    hipLaunchKernelGGL(edge_wgrad_reduce_kernel, dim3(JC / 64), dim3(64 * EW_G), 0, s, *d, d->ws, p.grid, p.JT * 16, d->C);
     return VG_LAUNCH_RC();
 }

@@ -390,6 +390,36 @@ __global__ __launch_bounds__(256) void bce_kernel(const float* __restrict__ p, f
     }
 }
 
+// The Discriminator loss of a grouped pass (vaegan_code.py:98-103): p = [real half | fake half], loss = BCE(real half, t0) +
+// BCE(fake half, t1) -- two bce_kernel launches' worth in one (same thread mapping per half, same order of the f64 sums,
+// loss = v0 + v1 in f32 as the accumulating second launch computed it: bit-identical).
+__global__ __launch_bounds__(256) void bce_pair_kernel(const float* __restrict__ p, float t0, float t1, int B, float gscale,
+                                                       float* __restrict__ loss, int accumulate, float* __restrict__ dp) {
+    __shared__ double red[2][4];
+    float out = 0.f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float target = h == 0 ? t0 : t1;
+        double s = 0.0;
+        for (int b = threadIdx.x; b < B; b += blockDim.x) {
+            const float pv = p[h * B + b];
+            const float l1 = fmaxf(logf(pv), -100.f);
+            const float l2 = fmaxf(logf(1.f - pv), -100.f);
+            s += (double)(-(target * l1 + (1.f - target) * l2));
+            if (dp) dp[h * B + b] = gscale * ((pv - target) / fmaxf((1.f - pv) * pv, 1e-12f)) / (float)B;
+        }
+        s = wave_sum_d(s);
+        if ((threadIdx.x & 63) == 0) red[h][threadIdx.x >> 6] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float v0 = (float)((red[0][0] + red[0][1] + red[0][2] + red[0][3]) / (double)B);
+        const float v1 = (float)((red[1][0] + red[1][1] + red[1][2] + red[1][3]) / (double)B);
+        out = accumulate ? loss[0] + v0 : v0;
+        loss[0] = out + v1;
+    }
+}
+
 // WGAN critic / generator losses (gan_code.py:306-315, :328): loss (+)= sign * mean(p), dp = sign * gscale / B
 __global__ __launch_bounds__(256) void mean_loss_kernel(const float* __restrict__ p, float sign, int B, float gscale,
                                                         float* __restrict__ loss, int accumulate,
@@ -719,6 +749,14 @@ extern "C" int vg_bce_forward_backward(const float* p, float target, int B, floa
                                        float* dp, void* stream) {
     VG_CHECK_ARG(p && loss && B > 0, VG_EINVAL);
     hipLaunchKernelGGL(bce_kernel, dim3(1), dim3(256), 0, vg_stream(stream), p, target, B, gscale, loss, accumulate, dp);
+    return VG_LAUNCH_RC();
+}
+
+extern "C" int vg_bce_pair_forward_backward(const float* p, float target0, float target1, int B, float gscale, float* loss,
+                                            int accumulate, float* dp, void* stream) {
+    VG_CHECK_ARG(p && loss && B > 0, VG_EINVAL);
+    hipLaunchKernelGGL(bce_pair_kernel, dim3(1), dim3(256), 0, vg_stream(stream), p, target0, target1, B, gscale, loss,
+                       accumulate, dp);
     return VG_LAUNCH_RC();
 }
 

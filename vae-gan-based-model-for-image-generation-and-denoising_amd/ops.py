@@ -792,6 +792,15 @@ def bce_forward_backward(p, target, gscale, loss, accumulate, want_grad, out=Non
     return dp
 
 
+def bce_pair_forward_backward(p_both, target0, target1, gscale, loss, out):
+    """loss[0] = BCE(p_both[:B], target0) + BCE(p_both[B:], target1); out [2B] <- the gradients.  One launch."""
+    _need_cuda(p_both, loss, out)
+    B = p_both.numel() // 2
+    L.check(L.load().vg_bce_pair_forward_backward(p_both.data_ptr(), target0, target1, B, gscale, loss.data_ptr(), 0,
+                                                  out.data_ptr(), L.stream_ptr()), "vg_bce_pair_forward_backward")
+    return out
+
+
 def mean_forward_backward(p, sign, gscale, loss, accumulate, want_grad, out=None):
     """loss (+)= sign*mean(p); returns dp = sign*gscale/B (WGAN losses, gan_code.py:306-315, :328)."""
     _need_cuda(p, loss, out)

@@ -200,8 +200,7 @@ class VAEGANTrainer:
             if grouped:
                 p_both, c_both = D.engine_forward(both, B, groups=2)                           # .detach(): no dx below
                 dp = torch.empty_like(p_both)
-                ops.bce_forward_backward(p_both[:B], self.real_label, 1.0, slot, False, True, out=dp[:B])
-                ops.bce_forward_backward(p_both[B:], self.fake_label, 1.0, slot, True, True, out=dp[B:])
+                ops.bce_pair_forward_backward(p_both, self.real_label, self.fake_label, 1.0, slot, dp)   # :98-103, one launch
                 D._engine.backward(c_both, dp, False, sink, on_grads=self._grad_hook(self.opt_D, D))
             else:
                 p_real, c_real = D.engine_forward(real_noisy, B)
