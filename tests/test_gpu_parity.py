@@ -888,3 +888,27 @@ def test_batchnorm_backward_sums_in_the_data_gradient_epilogue_train_like_the_de
     assert torch.equal(outs[0][0], outs[1][0])                       # the first iteration's losses precede any update
     torch.testing.assert_close(outs[1][1], outs[0][1], rtol=5e-3, atol=1e-3)
     assert abs(kernels[0] - kernels[1]) <= 1e-3 * abs(kernels[0]) + 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("graphed", [False, True])
+def test_side_stream_schedule_leaves_the_iteration_bit_identical(monkeypatch, graphed):
+    """VG_OVERLAP=3 (the Generator's Adam step + operand re-pack and the dead Discriminator
+    weight gradients beside the Encoder's backward, on the side stream / as a side graph) only reorders independent launches: three bf16
+    training iterations leave losses, every parameter and every Adam moment bit-identical to the serial schedule."""
+    outs = []
+    for mode in ("0", "3"):
+        monkeypatch.setenv("VG_OVERLAP", mode)
+        V.configure_seed(42)
+        e, g, d, tr = build(64, dtype="bf16")
+        assert tr.overlap == int(mode)
+        x = torch.randn(8, 3, 64, 64, generator=torch.Generator().manual_seed(3)).clamp(-1, 1).to(DEV)
+        step = tr.train_step_graphed if graphed else tr.train_step
+        ls = [step(x, 60)[:5].clone() for _ in range(3)]
+        torch.cuda.synchronize()
+        state = [torch.stack(ls).cpu()]
+        for o in (tr.opt_E, tr.opt_G, tr.opt_D):
+            state += [o.flat_p.cpu().clone(), o.exp_avg.cpu().clone(), o.exp_avg_sq.cpu().clone(), o.flat_g.cpu().clone()]
+        outs.append(state)
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
