@@ -550,9 +550,10 @@ def test_patch_gather_gemm_equals_reference_and_gather_path(ops, monkeypatch, ki
     for mode in ("gather", variant):
         monkeypatch.setenv("VG_GG_PATCH", "0" if mode == "gather" else "1")
         monkeypatch.setenv("VG_PATCH256_MIN", "1" if mode == "patch256" else "2000000000")
+        monkeypatch.setenv("VG_PATCH256X64_MIN", "1" if mode == "patch256" else "2000000000")    # 256 x 64 for 33..64 channels
         Y, st, nparts = ops.gather_gemm(gg, X, Wp, dtype, want_stats=True)
         M = gg.B * gg.GH * gg.GW
-        # 256-row tiles only where the 8-wave variant applies (N > 64 and a patch of <= 384 pixels), else 128-row tiles
+        # 256-row tiles only where an 8-wave variant applies (N > 32 and a patch of <= 384 pixels), else 128-row tiles
         assert nparts in ((gg.nphase * (M // 128),) if mode != "patch256" else (gg.nphase * (M // 128), gg.nphase * (M // 256)))
         outs[mode] = (from_nhwc(Y.double().cpu(), nout), st[: nparts * 2 * nout].view(nparts, 2, nout).double().sum(0).cpu())
     close(outs[variant][0], ref, dtype)
@@ -601,7 +602,7 @@ def test_stationary_gather_gemm_equals_reference_and_patch_path(ops, monkeypatch
             assert nparts <= 256 and (M // 128) % (nparts // gg.nphase) == 0, nparts       # one slab row per workgroup
             assert ops.gather_gemm_tile_m(gg, X, Wp, dtype) == (M // 128) // (nparts // gg.nphase) * 128
         else:
-            assert nparts == gg.nphase * (M // 128)
+            assert nparts in (gg.nphase * (M // 128), gg.nphase * (M // 256))      # 128- or (>= 512 tiles) 256-row patch tiles
         outs[mode] = (from_nhwc(Y.double().cpu(), nout), st[: nparts * 2 * nout].view(nparts, 2, nout).double().sum(0).cpu())
     close(outs["stationary"][0], ref, dtype)
     assert torch.equal(outs["stationary"][0], outs["patch"][0])      # same products in the same order (chunk, tap)

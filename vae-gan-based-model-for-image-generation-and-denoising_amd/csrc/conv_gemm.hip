@@ -716,6 +716,11 @@ inline int patch256_min() {
     return e ? atoi(e) : 256;               // 256 x 128 tiles where every CU gets at least one (step sweep: 128 / 192 / 256 / 384 -> 38.3 / 38.6 / 38.7 / 38.7k img/s)
 }
 
+inline int patch256x64_min() {
+    const char* e = getenv("VG_PATCH256X64_MIN");
+    return e ? atoi(e) : 512;               // G4 forward 63.9 -> 63.0 us, D1 data gradient 30.9 -> 28.4 (2B) and 17.8 -> 15.9 (B)
+}
+
 inline TileCfg pick_tile(const vg_gg_desc* d, bool bf16 = false, bool fp8 = false) {
     const int M = d->B * d->GH * d->GW;
     const int N = d->N;
@@ -731,8 +736,11 @@ inline TileCfg pick_tile(const vg_gg_desc* d, bool bf16 = false, bool fp8 = fals
     if (N <= 32) return {128, 32};
     // 256 x 128 exists only as the patch kernel (bf16, LDS-DMA): 8 waves share every weight tile
     PatchGeo pg;
-    // (a 256 x 64 instantiation for N <= 64 exists -- ggp_kernel<4, 64> -- but measured no better than 128 x 64
-    // on the step, so it is not selected)
+    // 256 x 64 for 33..64 output channels (ggp_kernel<4, 64>: 80 KB of stage buffers, two 8-wave workgroups per CU,
+    // every weight tile shared by 256 rows)
+    if (bf16 && N > 32 && N <= 64 && use_patch() && use_dma() && d->zeros != nullptr &&
+        tiles_of(M, N, 256, 64) * ph >= patch256x64_min() && patch_geometry(d, 256, &pg))
+        return {256, 64};
     if (bf16 && N > 64 && use_patch() && use_dma() && d->zeros != nullptr &&
         tiles_of(M, N, 256, 128) * ph >= patch256_min() && patch_geometry(d, 256, &pg))
         return {256, 128};

@@ -40,6 +40,17 @@ __device__ __forceinline__ void gp_wait(int n) {
     else VG_WAITCNT_VM(0);
 }
 
+// Waves per SIMD the register allocation must leave room for: the narrow variants whose stage buffers are exactly 40 KB
+// (128 rows) / 80 KB (256 rows) run FOUR / TWO workgroups per CU = 4 waves per SIMD (<= 128 registers).
+constexpr int gp_min_waves(int WM, int BN, int NR_) {
+#ifdef VG_GP_OCC3           // A/B build: the occupancy of the kernels before the overlaid pixel table (3 workgroups per CU)
+    return WM == 4 ? 2 : 1;
+#endif
+    if (GP_TPS != 2) return WM == 4 ? 2 : 1;
+    if (WM == 4) return BN <= 64 ? 4 : 2;
+    return (2 * (NR_ ? NR_ : 4) * 4096 + 256 * BN <= 40960) ? 4 : 1;
+}
+
 // WM = 2: 128-row tile, 4 waves, patch <= 192 pixels, 48.5 KB LDS (3 workgroups per CU).
 // WM = 4: 256-row tile, 8 waves sharing every weight tile (half the weight traffic per FLOP), patch <= 384 pixels,
 //         all four taps of a chunk per barrier, 113 KB LDS: ONE workgroup (8 waves, up to 256 registers each) per CU.
@@ -47,13 +58,13 @@ __device__ __forceinline__ void gp_wait(int n) {
 //         with two taps per barrier it was on par; with four taps per barrier it wins where the launch has >= 384
 //         tiles (G3 fprop 742 -> 780, G4 dgrad 689 -> 750 TFLOP/s) and loses at 256 tiles (G2 fprop 835 -> 806).
 template <int WM, int BN = GP_BN, int NR_ = 0>       // NR_: patch DMA rounds (0 = by tile shape); 3 where the patch has <= 192 pixels
-__global__ __launch_bounds__(128 * WM, WM == 4 ? 2 : 1) void ggp_kernel(const vg_gg_desc d, const PatchGeo g) {
+__global__ __launch_bounds__(128 * WM, gp_min_waves(WM, BN, NR_)) void ggp_kernel(const vg_gg_desc d, const PatchGeo g) {
     // BN = 128: wave tile 64 x 64; BN = 64 (layers with <= 64 output channels): wave tile 64 x 32; BN = 32: 64 x 16
     constexpr int BM = 64 * WM, WN = 2, TM = 4, TN = BN / 32, NT = 128 * WM, BST = BN * 64, WNC = BN / 2;
     constexpr int NR = NR_ ? NR_ : ((WM == 4 || GP_TPS != 2) ? 3 : 4);   /* WM == 4: 3 rounds of 512 lanes = 384 pixels */   // patch DMA rounds: 192 (3) or 256 (4) pixels per 128 rows
     constexpr int GP_PBUF = NR * NT * 16;           // NR rounds of NT lanes x 16 B
     constexpr int TPS = (WM == 4 && GP_TPS == 2) ? 4 : GP_TPS;   // 8 waves, one workgroup per CU: all 4 taps per barrier
-    constexpr int NB = TPS == 2 ? 2 : 3, BSTAGE = TPS * BST;
+    constexpr int NB = TPS >= 2 ? 2 : 3, BSTAGE = TPS * BST;   // (the TPS >= 2 loop alternates two slots)
     constexpr int BJ = (BN * 4 + NT - 1) / NT;      // weight-tile DMA instructions per wave and tap (2 / 1)
     // 256 x 64: the 64-row weight tile needs only 256 of the 512 lanes -> waves 4-7 skip the weight DMA (legal here:
     // that variant never uses counted vmcnt waits, every stage drains with vmcnt(0))
@@ -61,10 +72,17 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 2 : 1) void ggp_kernel(const vg
     static_assert(BN == 128 || BN == 64 || BN == 32, "supported shapes");
     static_assert(!B_HALF || TPS >= 2, "partial weight issue needs the drain-every-stage loop");
     // [patch buffers 2 x 12|24 KB][weight ring 3 x 8 KB][output-pixel table]
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * GP_PBUF + NB * BSTAGE + BM * 4];
+    // OVL (narrow tiles; 64 wide with 3 patch rounds and 32 wide: exactly 40 KB of stage buffers): the epilogue's output-pixel table lives in
+    // the weight-ring slot the LAST stage does not read, so that FOUR workgroups fit a CU's 160 KB (the kernel is bound
+    // by the LDS-DMA bytes in flight per CU: short-K tiles wait ~1 us for every stage they issue, section 9).
+    #ifdef VG_GP_OCC3
+    constexpr bool OVL = false;
+#else
+    constexpr bool OVL = (TPS >= 2 && BN <= 64);
+#endif
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * GP_PBUF + NB * BSTAGE + (OVL ? 0 : BM * 4)];
     unsigned char* const pbuf = smem;
     unsigned char* const bring = smem + 2 * GP_PBUF;
-    int* const opix_tab = reinterpret_cast<int*>(smem + 2 * GP_PBUF + NB * BSTAGE);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -100,6 +118,8 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 2 : 1) void ggp_kernel(const vg
     const int ncls = g.ncy * g.ncx;
     const int J = ncls * g.nct;                                 // chunks
     const int S = J * 4;                                        // tap stages
+    // stage s of the TPS >= 2 loop reads ring slot s & 1; J * (4 / TPS) stages -> the other slot is free from the last barrier on
+    int* const opix_tab = reinterpret_cast<int*>(OVL ? bring + ((J * (4 / TPS)) & 1) * BSTAGE : smem + 2 * GP_PBUF + NB * BSTAGE);
 
     // ---- weight-tile DMA lanes: rows lrow, lrow + 64; source unit swizzled by the row (as gg_kernel) ----
     const int lrow = tid >> 2;
@@ -324,12 +344,26 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 2 : 1) void ggp_kernel(const vg
     }
 
     // ---------------- epilogue (as gg_kernel<bf16, 128, 128>) ----------------
+#ifdef VG_ABL_EPI_LGKM            // timing-only: workgroup barriers that do not wait for outstanding global stores
+#define GP_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
+#else
+#define GP_SYNC() __syncthreads()
+#endif
 #ifdef VG_ABL_NO_EPI
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(acc[i][j]));
     return;
+#endif
+#ifdef VG_ABL_EPI_RUNTIME_SKIP    // timing-only: the epilogue is compiled (same registers, same main loop) but never executed
+    if (d.B > 0) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(acc[i][j]));
+        return;
+    }
 #endif
     typedef ElemT<VG_BF16> E;
     constexpr int ESZ = 2;
@@ -338,7 +372,11 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 2 : 1) void ggp_kernel(const vg
         const int m = m0 + r;
         int op = -1;
         if (m < M) {
+#ifdef VG_ABL_EPI_FLATOP
+            if (true) {
+#else
             if (flat) {
+#endif
                 op = m;
             } else {
                 const int b = m / GHW;
@@ -372,9 +410,13 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 2 : 1) void ggp_kernel(const vg
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[i][j][r] = act_fwd(acc[i][j][r], d.act, d.act_slope);
     }
-    __syncthreads();                                   // opix_tab visible; main-loop LDS reads are done
+    GP_SYNC();                                   // opix_tab visible; main-loop LDS reads are done
 
+#ifdef VG_ABL_EPI_NOSTATS
+    if (false) {
+#else
     if (d.stats != nullptr) {
+#endif
         float* red = reinterpret_cast<float*>(smem);   // [WM][BN][2]
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -398,7 +440,7 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 2 : 1) void ggp_kernel(const vg
                 red[(wm * BN + c) * 2 + 1] = b;
             }
         }
-        __syncthreads();
+        GP_SYNC();
         if (tid < BN && n0 + tid < d.N) {
             float a = 0.f, b = 0.f;
 #pragma unroll
@@ -407,11 +449,12 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 2 : 1) void ggp_kernel(const vg
             d.stats[(part * 2 + 0) * d.N + n0 + tid] = a;
             d.stats[(part * 2 + 1) * d.N + n0 + tid] = b;
         }
-        __syncthreads();
+        GP_SYNC();
     }
 
     constexpr int CPITCH = BN * ESZ + 16;              // BM rows x 272 B = 34 | 68 KB <= the 48 | 72 KB of stage buffers
     static_assert(BM * CPITCH <= 2 * GP_PBUF + NB * BSTAGE, "C tile does not fit in LDS");
+    static_assert(!OVL || (BM * CPITCH <= 2 * GP_PBUF && WM * BN * 8 <= 2 * GP_PBUF), "C tile / statistics scratch would overwrite the overlaid pixel table");
     constexpr int SEGS = BN * ESZ / 16;
     unsigned char* Yb = reinterpret_cast<unsigned char*>(d.Y);
     const int oc_bytes = d.OC * ESZ;
@@ -424,7 +467,11 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 2 : 1) void ggp_kernel(const vg
                 const int row = wm * 64 + i * 16 + fg * 4 + r;
                 const int col = wn * WNC + j * 16 + fr;
                 typename E::type* dst = reinterpret_cast<typename E::type*>(smem + row * CPITCH) + col;
+#ifdef VG_ABL_EPI_NOSTAGE
+                asm volatile("" ::"v"(acc[i][j][r]), "v"(dst));
+#else
                 *dst = E::from_f32(acc[i][j][r]);
+#endif
             }
     // BatchNorm-backward sums of the layer below (vg_gg_desc::bnb_*): this thread's segment is the same 8 channels in
     // every iteration (NT % SEGS == 0), so their coefficients and the 16 running sums live in registers.  The raw
@@ -456,7 +503,7 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 2 : 1) void ggp_kernel(const vg
         if (bnb && op >= 0 && cb < oc_bytes)
             yq[it] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(d.bnb_y) + (int64_t)op * oc_bytes + cb);
     }
-    __syncthreads();
+    GP_SYNC();
 #pragma unroll
     for (int it = 0; it < YIT; ++it) {
         const int u = tid + it * NT;
@@ -468,7 +515,11 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 2 : 1) void ggp_kernel(const vg
             if (d.mask_x != nullptr)
                 v = mask_segment<VG_BF16>(v, *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(d.mask_x) +
                                                                             (int64_t)op * oc_bytes + cb), d.mask_act, d.mask_slope);
+#ifdef VG_ABL_EPI_NOSTORE     // timing-only build: everything but the global store (v kept live)
+            asm volatile("" ::"v"(v));
+#else
             *reinterpret_cast<u32x4*>(Yb + (int64_t)op * oc_bytes + cb) = v;
+#endif
             if (bnb) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
@@ -484,11 +535,11 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 2 : 1) void ggp_kernel(const vg
     }
     if (bnb) {
         // workgroup sums: [NT][16] floats through LDS (the C tile has been read), then one thread per (segment, sum)
-        __syncthreads();
+        GP_SYNC();
         float* pr = reinterpret_cast<float*>(smem);
 #pragma unroll
         for (int k = 0; k < 8; ++k) { pr[tid * 16 + k] = b_s1[k]; pr[tid * 16 + 8 + k] = b_s2[k]; }
-        __syncthreads();
+        GP_SYNC();
         if (tid < SEGS * 16) {
             const int sg = tid >> 4, k = tid & 15;
             float a = 0.f;
@@ -499,6 +550,8 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 2 : 1) void ggp_kernel(const vg
         }
     }
 }
+
+#undef GP_SYNC
 
 inline bool use_patch() {                   // read per call: tests flip it inside one process
     const char* e = getenv("VG_GG_PATCH");
