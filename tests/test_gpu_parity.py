@@ -912,3 +912,34 @@ def test_side_stream_schedule_leaves_the_iteration_bit_identical(monkeypatch, gr
         outs.append(state)
     for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_garbage_collection_cannot_run_inside_a_graph_capture():
+    """A cyclic collection in the middle of a capture can destroy an older trainer's CUDAGraph (its private pool frees
+    device memory: not permitted while the thread captures -> the process aborts inside a destructor; seen once as
+    'Fatal Python error: Aborted ... Garbage-collecting' under train_step_graphed).  The capture collects first and keeps
+    the collector off until capture_end: with an older captured trainer left behind in a reference cycle and the
+    collector set to fire on every allocation, a second trainer still captures, replays and equals its eager twin."""
+    import gc
+    x = torch.randn(4, 3, 64, 64, generator=torch.Generator().manual_seed(5)).clamp(-1, 1).to(DEV)
+    V.configure_seed(42)
+    _, _, _, old = build(64, dtype="bf16")
+    for _ in range(3):
+        old.train_step_graphed(x, 60)
+    torch.cuda.synchronize()
+    old._cycle = old                       # only the cyclic collector can free it (and its graph) from now on
+    del old
+    thr = gc.get_threshold()
+    gc.set_threshold(1, 1, 1)
+    try:
+        V.configure_seed(42)
+        _, _, _, tr = build(64, dtype="bf16")
+        got = torch.stack([tr.train_step_graphed(x, 60)[:5].clone() for _ in range(3)]).cpu()
+        assert tr._graph is not None and gc.isenabled()
+    finally:
+        gc.set_threshold(*thr)
+    V.configure_seed(42)
+    _, _, _, ref = build(64, dtype="bf16")
+    want = torch.stack([ref.train_step(x, 60)[:5].clone() for _ in range(3)]).cpu()
+    assert torch.equal(got, want)

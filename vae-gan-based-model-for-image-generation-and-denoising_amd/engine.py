@@ -28,6 +28,27 @@ BN_MOMENTUM, BN_EPS = 0.1, 1e-5       # nn.BatchNorm2d defaults (main_vae.py:24,
 _SIDE = {}
 
 
+class no_gc_while_capturing:
+    """Context for a hipGraph capture: collect garbage first and keep Python's cyclic collector off until the capture has
+    ended.  A collection in the middle of a capture can destroy an older trainer's CUDAGraph or tensors of its private
+    pool; releasing device memory is not permitted while the thread captures, and the error surfaces inside a destructor,
+    i.e. as an abort of the process (seen once in four full test runs, under "Garbage-collecting" in the fault dump).
+    torch.cuda.graph() takes the same precaution (gc.collect() before capture_begin)."""
+
+    def __enter__(self):
+        import gc
+        gc.collect()
+        self._was = gc.isenabled()
+        gc.disable()
+        return self
+
+    def __exit__(self, *exc):
+        import gc
+        if self._was:
+            gc.enable()
+        return False
+
+
 def side_stream(device) -> "torch.cuda.Stream":
     """One low-priority stream per device for work that is off the critical path of a backward pass."""
     key = str(device)

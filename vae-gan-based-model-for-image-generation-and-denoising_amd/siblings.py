@@ -16,7 +16,7 @@ import torch
 
 from . import geometry as G
 from . import ops
-from .engine import GradSink, bump_weights_epoch
+from .engine import GradSink, bump_weights_epoch, no_gc_while_capturing
 
 
 class _Graphed:
@@ -51,7 +51,7 @@ class _Graphed:
         graph = torch.cuda.CUDAGraph()
         cap = torch.cuda.Stream(device=sin[0].device)
         cap.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(cap):
+        with no_gc_while_capturing(), torch.cuda.stream(cap):
             graph.capture_begin(capture_error_mode="thread_local")   # see trainer.py: other threads (c10d watchdog) may poll events
             sout = self.train_step(*sin, **scalars)
             graph.capture_end()

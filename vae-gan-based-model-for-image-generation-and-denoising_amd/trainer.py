@@ -13,7 +13,7 @@ import torch
 
 from . import geometry as G
 from . import ops
-from .engine import GradSink, side_stream
+from .engine import GradSink, no_gc_while_capturing, side_stream
 
 import os as _os
 _SIDE_INLINE = _os.environ.get("VG_SIDE_INLINE", "0") == "1"
@@ -384,7 +384,7 @@ class VAEGANTrainer:
             for o, st in zip((self.opt_E, self.opt_G, self.opt_D), steps):
                 o.steps = st
 
-        with torch.cuda.stream(cap):
+        with no_gc_while_capturing(), torch.cuda.stream(cap):
             self._cut_hook = cut
             self._side_hook = side_work if self.reducer is None else None
             try:
