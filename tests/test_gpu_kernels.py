@@ -614,6 +614,63 @@ def test_stationary_gather_gemm_equals_reference_and_patch_path(ops, monkeypatch
     close(from_nhwc(Y2.double().cpu(), nout), ref2, dtype)
 
 
+# ---- register-resident weights (csrc/conv_regweights.hpp): N = 64, K = 4 x 128, two workgroups per CU ------------------
+REGW_CASES = [  # kind, B, H (input)
+    ("convT", 32, 32),          # the Generator's ConvTranspose2d(128 -> 64) (gan_code.py:42): 3-round patches, 8 tiles per workgroup
+    ("conv_dgrad", 32, 64),     # data gradient of the Discriminator's Conv2d(64 -> 128) (gan_code.py:66)
+    ("convT", 8, 64),           # 64-wide grid: 4-round patches, 3-slot ring
+    ("conv_dgrad", 6, 32),      # 16-wide grid: 12 tiles per phase = 6 workgroups x 2 tiles
+    ("convT", 40, 16),          # 16-wide grid: tiles per phase (80) not a power of two
+]
+
+
+@pytest.mark.parametrize("kind,B,H", REGW_CASES)
+def test_register_weights_gather_gemm_equals_reference_and_patch_path(ops, monkeypatch, kind, B, H):
+    """ggr_kernel (a wave's weight slice lives in registers for the whole launch; persistent over M tiles; patch ring
+    with counted vmcnt; two workgroups per CU) against torch fp64 and, bit for bit, against the one-tile-per-workgroup
+    patch kernel: plain, with BatchNorm partial sums (one slab row per workgroup), with the fused activation of a
+    BatchNorm-less layer, and with the activation-backward mask of a data-gradient launch (arrives by LDS-DMA)."""
+    dtype, Cin, Cout = G.BF16, (128 if kind == "convT" else 64), (64 if kind == "convT" else 128)
+    g = torch.Generator().manual_seed(H * 3 + B)
+    if kind == "convT":
+        x = _q(torch.randn(B, Cin, H, H, generator=g), dtype)
+        w = torch.randn(Cin, Cout, 4, 4, generator=g) * 0.1
+        ref = F.conv_transpose2d(x, _q(w, dtype), None, stride=2, padding=1)
+        gg, pk = G.convT_fprop(B, H, H, Cin, Cout, 4, 2, 1, dtype)
+        oh = 2 * H
+    else:
+        x = _q(torch.randn(B, Cout, H // 2, H // 2, generator=g), dtype)
+        w = torch.randn(Cout, Cin, 4, 4, generator=g) * 0.1
+        ref = torch.nn.grad.conv2d_input((B, Cin, H, H), _q(w, dtype), x, stride=2, padding=1)
+        gg, pk = G.conv_dgrad(B, H, H, Cin, Cout, 4, 2, 1, dtype)
+        oh = H
+    Wp = ops.pack_weights(pk, w.to(DEV), dtype)
+    X = _dev(to_nhwc(x, gg.IC), dtype, ops)
+    below = _q(torch.randn(B, 64, oh, oh, generator=g), dtype)                  # activated output of the layer below (mask operand)
+    Xm = _dev(to_nhwc(below, 64), dtype, ops)
+    M = gg.B * gg.GH * gg.GW
+    monkeypatch.setenv("VG_TILE_MIN_WGS", "1")       # small problems still take the patch kernel (same summation order)
+    outs = {}
+    for mode in ("patch", "regw"):
+        monkeypatch.setenv("VG_GG_STATIONARY", "2" if mode == "regw" else "0")
+        Y, st, nparts = ops.gather_gemm(gg, X, Wp, dtype, want_stats=True)
+        if mode == "regw":
+            assert nparts <= 512 and (M // 128) % (nparts // gg.nphase) == 0, nparts       # one slab row per workgroup
+            assert ops.gather_gemm_tile_m(gg, X, Wp, dtype) == (M // 128) // (nparts // gg.nphase) * 128
+        stats = st[: nparts * 2 * 64].view(nparts, 2, 64).double().sum(0).cpu()
+        Ya, _, _ = ops.gather_gemm(gg, X, Wp, dtype, act=(2, 0.2))
+        Ym, _, _ = ops.gather_gemm(gg, X, Wp, dtype, mask=(Xm, 2, 0.2))
+        Yp, _, _ = ops.gather_gemm(gg, X, Wp, dtype)
+        outs[mode] = (from_nhwc(Y.double().cpu(), 64), stats, Ya.cpu(), Ym.cpu(), Yp.cpu())
+    close(outs["regw"][0], ref, dtype)
+    assert torch.equal(outs["regw"][0], outs["patch"][0])            # same products in the same order (chunk, tap)
+    torch.testing.assert_close(outs["regw"][1], outs["patch"][1], rtol=1e-5, atol=1e-2)
+    for k in (2, 3, 4):
+        assert torch.equal(outs["regw"][k], outs["patch"][k]), k
+    close(from_nhwc(outs["regw"][2].double(), 64), F.leaky_relu(ref, 0.2), dtype)
+    close(from_nhwc(outs["regw"][3].double(), 64), ref * torch.where(below.double() > 0, 1.0, 0.2), dtype)
+
+
 @pytest.mark.parametrize("kind,B,H,Cin,Cout", [("conv", 8, 16, 64, 128), ("convT", 8, 8, 128, 64), ("convT", 8, 1, 100, 1024),
                                                ("conv", 3, 16, 32, 64)])
 def test_workgroup_order_switches_do_not_change_results(ops, monkeypatch, kind, B, H, Cin, Cout):

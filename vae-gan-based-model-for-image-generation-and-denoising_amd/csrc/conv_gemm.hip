@@ -689,6 +689,7 @@ inline bool use_dma() {
 }
 
 #include "conv_stationary.hpp"
+#include "conv_regweights.hpp"
 
 inline int min_wgs() {                      // read per call (a few hundred ns): tests flip it inside one process
     const char* e = getenv("VG_TILE_MIN_WGS");
@@ -860,6 +861,8 @@ extern "C" int vg_gather_gemm_nparts(const vg_gg_desc* d, int dtype) {
     PatchGeo pg;
     StatPlan sp;
     if (stationary_plan(d, dtype, &pg, &sp)) return d->nphase * sp.wgs_per_phase;     // one slab row per workgroup
+    RegwPlan rp;
+    if (regw_plan(d, dtype, &pg, &rp)) return d->nphase * rp.wgs_per_phase;
     TileCfg t = pick_tile(d, dtype == VG_BF16, dtype == VG_FP8);
     const int M = d->B * d->GH * d->GW;
     return d->nphase * ((M + t.bm - 1) / t.bm);
@@ -872,6 +875,8 @@ inline int bnb_parts(const vg_gg_desc* d, int dtype) {
     PatchGeo pg;
     StatPlan sp;
     if (stationary_plan(d, dtype, &pg, &sp)) return 0;
+    RegwPlan rp;
+    if (regw_plan(d, dtype, &pg, &rp)) return 0;
     const int M = d->B * d->GH * d->GW;
     if (narrowk_ok(d, dtype)) return (64 % (d->N * 2 / 16) == 0) ? (M + NK_BM - 1) / NK_BM : 0;
     const TileCfg t = pick_tile(d, true, false);
@@ -901,6 +906,8 @@ extern "C" int vg_gather_gemm_tile_m(const vg_gg_desc* d, int dtype) {
     PatchGeo pg;
     StatPlan sp;
     if (stationary_plan(d, dtype, &pg, &sp)) return sp.tiles_per_wg * GS_BM;          // rows behind one slab row
+    RegwPlan rp;
+    if (regw_plan(d, dtype, &pg, &rp)) return rp.tiles_per_wg * GR_BM;
     return pick_tile(d, dtype == VG_BF16, dtype == VG_FP8).bm;
 }
 
@@ -924,6 +931,11 @@ extern "C" int vg_gather_gemm(const vg_gg_desc* d, int dtype, void* stream) {
     if (stationary_plan(d, dtype, &pg, &sp)) {                  // short-K transposed forms: weights resident in LDS
         if (d->stats) VG_CHECK_ARG(d->stats_capacity >= d->nphase * sp.wgs_per_phase, VG_EINVAL);
         return launch_stationary(d, pg, sp, vg_stream(stream));
+    }
+    RegwPlan rp;
+    if (regw_plan(d, dtype, &pg, &rp)) {                        // ... or in registers (two workgroups per CU)
+        if (d->stats) VG_CHECK_ARG(d->stats_capacity >= d->nphase * rp.wgs_per_phase, VG_EINVAL);
+        return launch_regw(d, pg, rp, vg_stream(stream));
     }
     TileCfg t = pick_tile(d, dtype == VG_BF16, dtype == VG_FP8);
     const SplitK sk = plan_splitk(d, dtype, t);

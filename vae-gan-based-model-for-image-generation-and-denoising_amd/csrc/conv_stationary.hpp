@@ -29,8 +29,8 @@ struct StatPlan { int wgs_per_phase, tiles_per_wg, nr; };
 // per CU hide each other's.  What this structure needs next is wave specialisation (a second wave per SIMD that owns
 // DMA issue and the epilogue, fed through LDS) -- DESIGN.md section 10.
 inline bool stationary_enabled() {
-    const char* e = getenv("VG_GG_STATIONARY");
-    return e ? atoi(e) != 0 : false;
+    const char* e = getenv("VG_GG_STATIONARY");      // 1 = this kernel; 2 (default) = register-resident weights, conv_regweights.hpp
+    return e ? atoi(e) == 1 : false;
 }
 
 // wait until at most `patches` x NR of this wave's vector-memory operations are outstanding (literal immediates)
