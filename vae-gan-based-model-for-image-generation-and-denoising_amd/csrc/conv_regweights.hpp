@@ -25,12 +25,15 @@ struct RegwPlan { int wgs_per_phase, tiles_per_wg, nr; };
 
 // OPT-IN (VG_GG_STATIONARY=2).  Measured on MI355X (S=64, B=128, tools/layer_bench.py): bit-identical to ggp_kernel
 // (tests/test_gpu_kernels.py::test_register_weights_gather_gemm_equals_reference_and_patch_path) but SLOWER -- G4 forward
-// 152 us against 64, D1 data gradient (2B) 44 against 29.  The design needs 128 registers for the weights plus ~130 for
-// accumulators, fragments, the patch cursors and the epilogue; hipcc (ROCm 7.2) hoists ~40 loop-invariant LDS / global
-// addresses on top and spills 76-300 bytes per lane at the 256-register cap of two waves per SIMD -- and every
-// scratch_load in the tile loop comes with an s_waitcnt vmcnt(0), which drains the patch ring the structure exists to
-// keep full.  Making it pay needs the weight fragments in AGPRs by hand (inline-asm MFMA operands) or half the weights
-// per wave (8 waves per workgroup, one workgroup per CU); neither was done in round 2.
+// 72 us against 64, D1 data gradient (2B) 39 against 29.  History: the first build needed 128 registers for the weights
+// plus ~150 for accumulators, fragments, cursors and the ~40 loop-invariant addresses hipcc hoists; at the 256-register
+// cap of two waves per SIMD it spilled 76-300 bytes per lane, and every scratch_load in the tile loop comes with an
+// s_waitcnt vmcnt(0) that drains the patch ring (152 / 44 us).  The addresses are now recomputed behind opaque zeros
+// (tz, cz) and the instantiations in use compile without scratch -- but the recomputation is ~100 VALU instructions
+// per 32 MFMAs, and with ONE wave of a workgroup per SIMD nothing hides it: ablation builds (tools/ablate.sh): no DMA
+// and no epilogue 38.6 us (MFMA bound 13.7), no epilogue 46.7, no DMA 64.0.  What it needs: the fragment addresses as
+// ds_read immediates (a patch image whose swizzle commutes with the tap shifts) or the weights pinned in AGPRs by hand
+// so that 16 address registers fit.  Not done in round 2.
 // 0 (default) off, 1 = weights resident in LDS (ggs_kernel, conv_stationary.hpp), 2 = weights resident in registers
 inline int stationary_mode() {
     const char* e = getenv("VG_GG_STATIONARY");
@@ -116,26 +119,12 @@ __global__ __launch_bounds__(GR_NT, 2) void ggr_kernel(const vg_gg_desc d, const
         const int ry = rr / d.GW;
         ppbase[i] = img * g.PIMG + ry * g.PW + (rr - ry * d.GW);
     }
-    // tile rows of this thread in the mask DMA and in the store loop: row(it) = 32 it + (tid >> 3), segment tid & 7.
-    // output pixel = tile base + o_inv[it] (the sub-pixel scatter is affine in the tile's first grid row)
-    int o_inv[4];
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int row = it * 32 + (tid >> 3);
-        const int per_img = g.R * d.GW;
-        const int img = row / per_img;
-        const int rr = row - img * per_img;
-        const int ry = rr / d.GW;
-        const int rx = rr - ry * d.GW;
-        o_inv[it] = (img * d.OH + ry * d.OSY + d.ooy[phase]) * d.OW + rx * d.OSX + d.oox[phase];
-    }
-    const int seg16 = (tid & 7) * 16;
     const int sh_y1 = d.DY > 0 ? 1 : 0, sh_x1 = d.DX > 0 ? 1 : 0;
 
     // ---- patch issue cursor: patches are numbered tile-major (tile, chunk); patch n lives in ring slot n % NSLOT ----
     const int t_first = widx * tiles_per_wg;
     const int n_patches = tiles_per_wg * J;
-    const unsigned char* a_cur[NR];
+    uint32_t a_off[NR];                                         // byte offset of the lane's next 16 bytes in X (rounds that read real data)
     uint32_t a_live = 0;
     auto patch_sources = [&](int tile) {
         const int m0 = tile * BM;
@@ -148,7 +137,7 @@ __global__ __launch_bounds__(GR_NT, 2) void ggr_kernel(const vg_gg_desc d, const
             const int iy = (gy0 + (int)(p_st[r] >> 8 & 255u)) * d.SY + cy;
             const int ix = (int)(p_st[r] >> 16 & 255u) * d.SX + cx;
             const bool ok = (p_st[r] >> 26 & 1u) && b < d.B && (unsigned)iy < (unsigned)d.IH && (unsigned)ix < (unsigned)d.IW;
-            a_cur[r] = ok ? Xb + ((uint32_t)((b * d.IH + iy) * d.IW + ix) * pix_bytes + (p_st[r] >> 24 & 3u) * 16u) : Zp;
+            a_off[r] = (uint32_t)((b * d.IH + iy) * d.IW + ix) * pix_bytes + (p_st[r] >> 24 & 3u) * 16u;
             a_live |= ok ? (1u << r) : 0u;
         }
     };
@@ -158,11 +147,12 @@ __global__ __launch_bounds__(GR_NT, 2) void ggr_kernel(const vg_gg_desc d, const
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
 #ifndef VG_ABL_NO_A
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a_cur[r],
+            const unsigned char* src = (a_live >> r & 1u) ? Xb + a_off[r] : Zp;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(dst + (NT * r + 64 * wave_u) * 16),
                                              16, 0, 0);
 #endif
-            a_cur[r] += (a_live >> r & 1u) * 64u;
+            a_off[r] += 64u;
         }
         ++issued;
         if (++is_c == J) { is_c = 0; ++is_tile; if (issued < n_patches) patch_sources(is_tile); }
@@ -171,26 +161,51 @@ __global__ __launch_bounds__(GR_NT, 2) void ggr_kernel(const vg_gg_desc d, const
     f32x4 acc[TM][TN];
     // one chunk = 4 taps x (TM fragment reads, TM x TN MFMAs against the register-resident weights); the MFMA takes the
     // WEIGHT fragment as its row operand: lane (fr, fg) then holds pixel 16 i + fr, channels 16 j + 4 fg + 0..3
-    auto compute_chunk = [&](const unsigned char* sa, const u32x4 (&w)[4][TN]) {
+    auto load_frags = [&](const unsigned char* sa, int k, int z, u32x4 (&fa)[TM]) {
+        const int a = k >> 1, b = k & 1;
+        const int shy = a ? sh_y1 : 1 - sh_y1, shx = b ? sh_x1 : 1 - sh_x1;
+        const int tapoff = shy * g.PW + shx;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int pp = ppbase[i] + tapoff + z;              // z: an opaque 0 -- keeps the 16 fragment addresses out of registers
+            fa[i] = *reinterpret_cast<const u32x4*>(sa + pp * 64 + (((lane >> 4) ^ ((pp >> 1) & 3)) << 4));
+        }
+    };
+    auto mfma_frags = [&](const u32x4 (&fa)[TM], const u32x4 (&w)[TN]) {
 #ifndef VG_ABLATE_COMPUTE
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int a = k >> 1, b = k & 1;
-            const int shy = a ? sh_y1 : 1 - sh_y1, shx = b ? sh_x1 : 1 - sh_x1;
-            const int tapoff = shy * g.PW + shx;
-            u32x4 fa[TM];
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int pp = ppbase[i] + tapoff;
-                fa[i] = *reinterpret_cast<const u32x4*>(sa + pp * 64 + ((fg ^ ((pp >> 1) & 3)) << 4));
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[j]),
+                                                                   __builtin_bit_cast(bf16x8, fa[i]), acc[i][j], 0, 0, 0);
+#endif
+    };
+    // the reads of tap k+1 are issued before the MFMAs of tap k (two fragment sets): with one wave of this workgroup per
+    // SIMD the LDS latency is otherwise paid four times per chunk
+    auto compute_chunk = [&](const unsigned char* sa, const u32x4 (&w)[4][TN], const int z) {
+        u32x4 fa0[TM], fa1[TM];
+        load_frags(sa, 0, z, fa0);
+        load_frags(sa, 1, z, fa1);
+        mfma_frags(fa0, w[0]);
+        load_frags(sa, 2, z, fa0);
+        mfma_frags(fa1, w[1]);
+        load_frags(sa, 3, z, fa1);
+        mfma_frags(fa0, w[2]);
+        mfma_frags(fa1, w[3]);
+#if !defined(VG_ABLATE_COMPUTE) && !defined(VG_NO_SCHED)
+        // the order the scheduler has to keep (0x100 = DS read, 0x008 = MFMA)
+        __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+#pragma unroll
+            for (int h = 0; h < TM; ++h) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[k][j]),
-                                                                       __builtin_bit_cast(bf16x8, fa[i]), acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - TM, 0);
         }
+        __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
 #endif
     };
 
@@ -217,6 +232,24 @@ __global__ __launch_bounds__(GR_NT, 2) void ggr_kernel(const vg_gg_desc d, const
         const int gy0 = (m0 - b0 * GHW) / d.GW;
         const int obase = (b0 * d.OH + gy0 * d.OSY) * d.OW;     // output pixel of a tile row = obase + o_inv
         int after_mask = 0;                                     // patches issued behind this tile's mask DMA
+        // tile rows of this thread in the mask DMA and in the store loop: row(it) = 32 it + (tid >> 3), segment tid & 7;
+        // output pixel = obase + o_inv[it].  Recomputed per tile behind an opaque 0 (tz) so that neither these nor the
+        // epilogue's LDS addresses stay in registers across the main loop (the weights leave no room for them).
+        int tz;
+        asm volatile("s_mov_b32 %0, 0" : "=s"(tz));
+        const int tidz = tid + tz;
+        int o_inv[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = it * 32 + (tidz >> 3);
+            const int per_img = g.R * d.GW;
+            const int img = row / per_img;
+            const int rr = row - img * per_img;
+            const int ry = rr / d.GW;
+            const int rx = rr - ry * d.GW;
+            o_inv[it] = (img * d.OH + ry * d.OSY + d.ooy[phase]) * d.OW + rx * d.OSX + d.oox[phase];
+        }
+        const int seg16 = (tidz & 7) * 16;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -237,7 +270,9 @@ __global__ __launch_bounds__(GR_NT, 2) void ggr_kernel(const vg_gg_desc d, const
                         (__attribute__((address_space(3))) void*)(cbuf + (it * 4 + wave_u) * 1040), 16, 0, 0);
             }
             if (issued < n_patches) { issue_patch(); ++after_mask; }   // into the slot patch q-1 has just left
-            compute_chunk(pring + (q % NSLOT) * PBUF, wf[c]);
+            int cz;
+            asm volatile("s_mov_b32 %0, 0" : "=s"(cz));
+            compute_chunk(pring + (q % NSLOT) * PBUF, wf[c], cz);
         }
 
         // ---------------- epilogue of the tile (the ring keeps filling underneath) ----------------
@@ -256,8 +291,8 @@ __global__ __launch_bounds__(GR_NT, 2) void ggr_kernel(const vg_gg_desc d, const
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int row = wm * 64 + i * 16 + fr;
-                const int col = wn * WNC + j * 16 + fg * 4;
+                const int row = wm * 64 + i * 16 + (tidz & 15);
+                const int col = wn * WNC + j * 16 + (tidz >> 4 & 3) * 4;
                 uint2* slot = reinterpret_cast<uint2*>(cbuf + gr_row_off(row) + col * 2);
                 uint2 mx = uint2{0u, 0u};
                 if (masked) mx = *slot;
@@ -283,7 +318,7 @@ __global__ __launch_bounds__(GR_NT, 2) void ggr_kernel(const vg_gg_desc d, const
         gs_lds_barrier();                                       // C tile visible
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            const int row = it * 32 + (tid >> 3);
+            const int row = it * 32 + (tidz >> 3);
             *reinterpret_cast<u32x4*>(Yb + (int64_t)(obase + o_inv[it]) * oc_bytes + seg16) =
                 *reinterpret_cast<const u32x4*>(cbuf + gr_row_off(row) + seg16);
         }
@@ -336,6 +371,8 @@ inline bool regw_plan(const vg_gg_desc* d, int dtype, PatchGeo* g, RegwPlan* rp)
     rp->wgs_per_phase = W;
     rp->tiles_per_wg = T / W;
     rp->nr = g->NPP <= 192 ? 3 : 4;
+    // only the instantiations that compile without scratch (a spill in the tile loop drains the patch ring)
+    if (rp->nr != 3 || (d->stats != nullptr && d->mask_x != nullptr)) return false;
     return true;
 }
 
