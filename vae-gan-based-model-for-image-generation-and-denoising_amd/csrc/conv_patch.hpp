@@ -75,7 +75,7 @@ __global__ __launch_bounds__(128 * WM, gp_min_waves(WM, BN, NR_)) void ggp_kerne
     // OVL (narrow tiles; 64 wide with 3 patch rounds and 32 wide: exactly 40 KB of stage buffers): the epilogue's output-pixel table lives in
     // the weight-ring slot the LAST stage does not read, so that FOUR workgroups fit a CU's 160 KB (the kernel is bound
     // by the LDS-DMA bytes in flight per CU: short-K tiles wait ~1 us for every stage they issue, section 9).
-    #ifdef VG_GP_OCC3
+#ifdef VG_GP_OCC3
     constexpr bool OVL = false;
 #else
     constexpr bool OVL = (TPS >= 2 && BN <= 64);

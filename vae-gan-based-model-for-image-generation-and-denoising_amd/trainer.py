@@ -7,6 +7,7 @@ parity runs or are drawn on the device.
     trainer = VAEGANTrainer(encoder, decoder, discriminator, opt_E, opt_Dec, opt_Dis)
     losses = trainer.train_step(real_images, epoch)          # device tensor, no host sync
 """
+import os
 from typing import Dict, Optional
 
 import torch
@@ -15,8 +16,7 @@ from . import geometry as G
 from . import ops
 from .engine import GradSink, no_gc_while_capturing, side_stream
 
-import os as _os
-_SIDE_INLINE = _os.environ.get("VG_SIDE_INLINE", "0") == "1"
+_SIDE_INLINE = os.environ.get("VG_SIDE_INLINE", "0") == "1"   # diagnostic for VG_OVERLAP: replay the side graph in order
 
 LOSS_NAMES = ("recon_loss", "kl_loss", "g_loss_adv", "d_loss_1", "d_loss_2")
 
@@ -67,17 +67,17 @@ class VAEGANTrainer:
         # second stream.  MEASURED SLOWER on MI355X (S=64, B=128, graph replay, interleaved A/B: 3.156 vs 3.079 ms):
         # like the per-layer side-stream weight gradients of round 1, concurrent grids cost more in lost L2/LDS
         # residency and queueing than the latency-bound Encoder chain leaves idle.
-        import os
         self.overlap_encoder_backward = os.environ.get("VG_OVERLAP_E", "0") == "1"
-        # VG_OVERLAP (bit mask; single-GPU schedule only, i.e. reducer is None): work that nothing before the end of the
-        # iteration waits for runs on the side stream beside the Encoder's backward, a chain of ~35 dependent kernels of
-        # 4-6 us each that leaves most of the chip idle:
+        # VG_OVERLAP (opt-in bit mask; single-GPU schedule only, i.e. reducer is None): work that nothing before the end
+        # of the iteration waits for runs on the side stream beside the Encoder's backward, a chain of 38 dependent
+        # kernels of 2-18 us each that leaves most of the chip idle:
         #   1  the Generator's Adam step and the re-pack of its GEMM operands (otherwise the first thing the NEXT
         #      iteration's Generator forward does),
         #   2  the (dead, vaegan_code.py:133) Discriminator weight gradients of the generator-loss pass as well.
         # Under hipGraph replay the side work is its OWN graph launched on the side stream between two segments of the
-        # main graph: a fork INSIDE one captured graph costs ~170 us per replay on ROCm 7.2 (every node of a graph with
-        # parallel branches is submitted with its own completion signal; measured with tools/ab_overlap.sh).
+        # main graph.  Bit-identical to the serial schedule and MEASURED SLOWER (+105...+150 us; a
+        # fork inside ONE captured graph costs even more; each extra graph boundary ~29 us; the wide grids of the side
+        # stream delay every kernel of the latency-bound chain they were meant to hide under).
         self.overlap = int(os.environ.get("VG_OVERLAP", "0"))
         self.losses = None
         self.noise = None               # ops.NoiseStream for the in-kernel randn_like draws (created on first use)
