@@ -51,7 +51,10 @@ constexpr int gp_min_waves(int WM, int BN, int NR_) {
     return (2 * (NR_ ? NR_ : 4) * 4096 + 256 * BN <= 40960) ? 4 : 1;
 }
 
-// WM = 2: 128-row tile, 4 waves, patch <= 192 pixels, 48.5 KB LDS (3 workgroups per CU).
+// WM = 2: 128-row tile, 4 waves, patch <= 256 pixels (4 DMA rounds) or <= 192 (NR_ = 3); LDS = 2 patch buffers + 2 weight
+//         slots of 2 taps: 64.5 KB at BN = 128 (2 workgroups per CU), 48 KB at BN = 64, exactly 40 KB for BN = 64 with 3
+//         rounds and for BN = 32 (FOUR workgroups per CU, <= 128 registers: gp_min_waves).
+// WM = 4, BN = 64: 256 x 64, 8 waves, 80 KB, TWO workgroups per CU (<= 128 registers), for launches with >= 512 such tiles.
 // WM = 4: 256-row tile, 8 waves sharing every weight tile (half the weight traffic per FLOP), patch <= 384 pixels,
 //         all four taps of a chunk per barrier, 113 KB LDS: ONE workgroup (8 waves, up to 256 registers each) per CU.
 //         History: with a 128-register cap (two workgroups per CU) it spilled and lost 30 %; at one workgroup per CU
