@@ -48,11 +48,16 @@ extern "C" {
 #define VG_ACT_LRELU   2   /* nn.LeakyReLU(slope)    main_vae.py:25, gan_code.py:62-82 */
 #define VG_ACT_TANH    3   /* nn.Tanh()              gan_code.py:50 (vg_tnconv epilogue only) */
 
-#define VG_ABI_VERSION 7   /* 2: vg_pack_desc.tile_start, SyncBN / WGAN / data-path entry points; 3: in-kernel noise (vg_*_rng);
+#define VG_ABI_VERSION 8   /* 2: vg_pack_desc.tile_start, SyncBN / WGAN / data-path entry points; 3: in-kernel noise (vg_*_rng);
                              4: vg_bn_finalize_act_forward, vg_bn_backward_finalize_apply;
-                             5: input prologue of vg_tn_desc / vg_ew_desc; 6: vg_gg_desc.bnb_*;
-                             7: vg_bce_pair_forward_backward */
+                             7: vg_bce_pair_forward_backward;
+                             8: round-3 prune -- the opt-in experiments of ABI 5 / 6 that measured slower (input prologue of
+                                vg_tn_desc / vg_ew_desc, vg_gg_desc.bnb_*) are gone from the descriptors; vg_reload_switches */
 int vg_abi_version(void);
+/* The library reads its optional kernel-selection switches (VG_* environment variables, DESIGN.md "Runtime switches")
+ * ONCE, when it is loaded; nothing on a launch path calls getenv.  A process that changes one of them afterwards
+ * (tests, A/B scripts) calls this to have them read again.  Returns 0. */
+int vg_reload_switches(void);
 /* Live kernel timing for the roofline report: while enabled, gather-GEMM (family 0) and wgrad (family 1)
  * launches carry a HIP start/stop event pair on their stream (hipExtLaunchKernelGGL); collect() synchronises,
  * sums the kernel times in ms, returns the launch count and resets the family.  Do not enable during capture. */
@@ -103,26 +108,10 @@ typedef struct vg_gg_desc {
     const void* mask_x;
     int32_t mask_act;
     float   mask_slope;
-    /* BatchNorm-backward sums of the layer BELOW in the epilogue (ABI 6; optional; a data-gradient launch whose output Y
-     * is dL/d(activated output) of a layer with BatchNorm + activation): bnb_y is that layer's raw conv output (same
-     * [B][OH][OW][OC] layout), bnb_coeffs its [4][N] mean | invstd | scale | shift; the kernel writes, per M tile, the
-     * partial sums ( sum dz | sum dz * xhat ), dz = Y * act'(scale*y + shift), xhat = (y - mean) * invstd, into
-     * bnb_partial [nparts][2][N] -- exactly what vg_bn_act_backward_reduce would have produced in a pass of its own over
-     * Y and y.  Honoured only by the kernels listed at vg_gather_gemm_bnb_nparts (which returns 0 otherwise: the caller
-     * then runs the reduce pass). */
-    const void*  bnb_y;
-    const float* bnb_coeffs;
-    float*       bnb_partial;
-    int32_t bnb_act;
-    float   bnb_slope;
-    int32_t bnb_capacity;     /* number of [2][N] rows bnb_partial can hold */
 } vg_gg_desc;
 
 /* Number of stats slabs vg_gather_gemm will write for this descriptor (host-only query). */
 int vg_gather_gemm_nparts(const vg_gg_desc* d, int dtype);
-/* Rows of bnb_partial the launch of this descriptor will write if bnb_y is set -- > 0 only where the launch runs on a
- * kernel with that epilogue (bf16: the narrow-K direct kernel and the patch gather-GEMM, no split-K) -- else 0. */
-int vg_gather_gemm_bnb_nparts(const vg_gg_desc* d, int dtype);
 /* Kernel family a launch of this descriptor belongs to (for the roofline accounting of vg_timing_*):
  * 0 = gather-GEMM (MFMA-bound), 2 = edge layer (3-channel image side, HBM-bound: conv_narrowk.hpp). */
 int vg_gather_gemm_family(const vg_gg_desc* d, int dtype);
@@ -302,13 +291,6 @@ typedef struct vg_tn_desc {
     int32_t draw;
     float sigma;
     int32_t B, IH, IW, C, N, K, S, P, OH, OW, OC, Wpitch, act;
-    /* input prologue (ABI 5): X is the RAW output of the layer below and the kernel applies that layer's BatchNorm +
-     * activation while loading it, x' = act_in(in_scale[c] * x + in_shift[c]) rounded to bf16 -- bit for bit what
-     * vg_bn_act_forward would have stored, without the pass.  in_scale == NULL: X is used as it is. */
-    const float* in_scale;
-    const float* in_shift;
-    int32_t in_act;
-    float in_slope;
 } vg_tn_desc;
 /* Weight gradient of the edge layers, bf16 operands, f32 result:
  *     dW[c*s_c + n*s_n + kh*K + kw] (+)= sum_{b,py,px} Wd[b][py][px][c] * Nr[b][py*S - P + kh][px*S - P + kw][n]
@@ -326,11 +308,6 @@ typedef struct vg_ew_desc {
     int64_t ws_bytes;
     const void* zeros;
     int32_t B, WH, WW, C, NH, NW, N, K, S, P, s_c, s_n, accumulate;
-    /* prologue on the WIDE operand (ABI 5), as vg_tn_desc: Wd' = act_in(in_scale[c] * Wd + in_shift[c]) */
-    const float* in_scale;
-    const float* in_shift;
-    int32_t in_act;
-    float in_slope;
 } vg_ew_desc;
 int64_t vg_edge_wgrad_ws_bytes(const vg_ew_desc* d);
 int vg_edge_wgrad(const vg_ew_desc* d, void* stream);

@@ -514,7 +514,7 @@ PATCH_CASES = [  # kind, B, H (input), Cin, Cout      (k4 s2 p1 everywhere; all 
 
 @pytest.mark.parametrize("kind,B,H,Cin,Cout", PATCH_CASES)
 @pytest.mark.parametrize("variant", ["patch128", "patch256"])
-def test_patch_gather_gemm_equals_reference_and_gather_path(ops, monkeypatch, kind, B, H, Cin, Cout, variant):
+def test_patch_gather_gemm_equals_reference_and_gather_path(ops, vg_switch, kind, B, H, Cin, Cout, variant):
     """Both patch forms (one phase of the 4-phase transposed form; the stride-2 4x4 conv as 4 input-parity classes),
     4-wave 128-row and 8-wave 256-row tiles, against torch fp64 and against the per-tap gather kernel."""
     dtype = G.BF16
@@ -545,12 +545,12 @@ def test_patch_gather_gemm_equals_reference_and_gather_path(ops, monkeypatch, ki
         nout = Cin
     Wp = ops.pack_weights(pk, w.to(DEV), dtype)
     X = _dev(to_nhwc(x, gg.IC), dtype, ops)
-    monkeypatch.setenv("VG_TILE_MIN_WGS", "1")       # small problems still take the 128 x 128 tile
+    vg_switch("VG_TILE_MIN_WGS", "1")       # small problems still take the 128 x 128 tile
     outs = {}
     for mode in ("gather", variant):
-        monkeypatch.setenv("VG_GG_PATCH", "0" if mode == "gather" else "1")
-        monkeypatch.setenv("VG_PATCH256_MIN", "1" if mode == "patch256" else "2000000000")
-        monkeypatch.setenv("VG_PATCH256X64_MIN", "1" if mode == "patch256" else "2000000000")    # 256 x 64 for 33..64 channels
+        vg_switch("VG_GG_PATCH", "0" if mode == "gather" else "1")
+        vg_switch("VG_PATCH256_MIN", "1" if mode == "patch256" else "2000000000")
+        vg_switch("VG_PATCH256X64_MIN", "1" if mode == "patch256" else "2000000000")    # 256 x 64 for 33..64 channels
         Y, st, nparts = ops.gather_gemm(gg, X, Wp, dtype, want_stats=True)
         M = gg.B * gg.GH * gg.GW
         # 256-row tiles only where an 8-wave variant applies (N > 32 and a patch of <= 384 pixels), else 128-row tiles
@@ -562,118 +562,9 @@ def test_patch_gather_gemm_equals_reference_and_gather_path(ops, monkeypatch, ki
     torch.testing.assert_close(outs[variant][1], outs["gather"][1], rtol=1e-5, atol=1e-3)
 
 
-# ---- weight-stationary persistent gather-GEMM (csrc/conv_stationary.hpp): short-K transposed forms, N = 64 ----------
-STATIONARY_CASES = [  # kind, B, H (input), Cin, Cout
-    ("convT", 32, 32, 128, 64),        # the Generator's ConvTranspose2d(128 -> 64) shape class (gan_code.py:42): 3-round patches
-    ("conv_dgrad", 32, 64, 64, 128),   # data gradient of the Discriminator's Conv2d(64 -> 128) (gan_code.py:66)
-    ("convT", 8, 64, 64, 64),          # 64-wide grid: 4-round patches, 2 chunks
-    ("convT", 8, 64, 32, 64),          # one chunk per tile
-    ("convT", 40, 32, 96, 64),         # tiles per phase not a power of two (320 = 64 workgroups x 5 tiles), 3 chunks
-]
-
-
-@pytest.mark.parametrize("kind,B,H,Cin,Cout", STATIONARY_CASES)
-def test_stationary_gather_gemm_equals_reference_and_patch_path(ops, monkeypatch, kind, B, H, Cin, Cout):
-    """ggs_kernel (weights resident in LDS, persistent over M tiles, patch ring with counted vmcnt) against torch fp64
-    and against the one-tile-per-workgroup patch kernel; BatchNorm partial sums: one slab row per workgroup."""
-    dtype = G.BF16
-    g = torch.Generator().manual_seed(H * 5 + Cin)
-    if kind == "convT":
-        x = _q(torch.randn(B, Cin, H, H, generator=g), dtype)
-        w = torch.randn(Cin, Cout, 4, 4, generator=g) * 0.1
-        ref = F.conv_transpose2d(x, _q(w, dtype), None, stride=2, padding=1)
-        gg, pk = G.convT_fprop(B, H, H, Cin, Cout, 4, 2, 1, dtype)
-        nout = Cout
-    else:
-        x = _q(torch.randn(B, Cout, H // 2, H // 2, generator=g), dtype)
-        w = torch.randn(Cout, Cin, 4, 4, generator=g) * 0.1
-        ref = torch.nn.grad.conv2d_input((B, Cin, H, H), _q(w, dtype), x, stride=2, padding=1)
-        gg, pk = G.conv_dgrad(B, H, H, Cin, Cout, 4, 2, 1, dtype)
-        nout = Cin
-    assert nout == 64
-    Wp = ops.pack_weights(pk, w.to(DEV), dtype)
-    X = _dev(to_nhwc(x, gg.IC), dtype, ops)
-    M = gg.B * gg.GH * gg.GW
-    outs = {}
-    for mode in ("patch", "stationary"):
-        monkeypatch.setenv("VG_GG_STATIONARY", "1" if mode == "stationary" else "0")
-        Y, st, nparts = ops.gather_gemm(gg, X, Wp, dtype, want_stats=True)
-        if mode == "stationary":
-            assert nparts <= 256 and (M // 128) % (nparts // gg.nphase) == 0, nparts       # one slab row per workgroup
-            assert ops.gather_gemm_tile_m(gg, X, Wp, dtype) == (M // 128) // (nparts // gg.nphase) * 128
-        else:
-            assert nparts in (gg.nphase * (M // 128), gg.nphase * (M // 256))      # 128- or (>= 512 tiles) 256-row patch tiles
-        outs[mode] = (from_nhwc(Y.double().cpu(), nout), st[: nparts * 2 * nout].view(nparts, 2, nout).double().sum(0).cpu())
-    close(outs["stationary"][0], ref, dtype)
-    assert torch.equal(outs["stationary"][0], outs["patch"][0])      # same products in the same order (chunk, tap)
-    torch.testing.assert_close(outs["stationary"][1], outs["patch"][1], rtol=1e-5, atol=1e-2)
-    # a second call on a dirty output buffer: nothing is left unwritten
-    monkeypatch.setenv("VG_GG_STATIONARY", "1")
-    Y2, _, _ = ops.gather_gemm(gg, X, Wp, dtype, bias=torch.full((64,), 0.5, device=DEV), act=(2, 0.2))
-    ref2 = F.leaky_relu(ref + 0.5, 0.2)
-    close(from_nhwc(Y2.double().cpu(), nout), ref2, dtype)
-
-
-# ---- register-resident weights (csrc/conv_regweights.hpp): N = 64, K = 4 x 128, two workgroups per CU ------------------
-REGW_CASES = [  # kind, B, H (input)
-    ("convT", 32, 32),          # the Generator's ConvTranspose2d(128 -> 64) (gan_code.py:42): 3-round patches, 8 tiles per workgroup
-    ("conv_dgrad", 32, 64),     # data gradient of the Discriminator's Conv2d(64 -> 128) (gan_code.py:66)
-    ("convT", 8, 64),           # 64-wide grid: 4-round patches, 3-slot ring
-    ("conv_dgrad", 6, 32),      # 16-wide grid: 12 tiles per phase = 6 workgroups x 2 tiles
-    ("convT", 40, 16),          # 16-wide grid: tiles per phase (80) not a power of two
-]
-
-
-@pytest.mark.parametrize("kind,B,H", REGW_CASES)
-def test_register_weights_gather_gemm_equals_reference_and_patch_path(ops, monkeypatch, kind, B, H):
-    """ggr_kernel (a wave's weight slice lives in registers for the whole launch; persistent over M tiles; patch ring
-    with counted vmcnt; two workgroups per CU) against torch fp64 and, bit for bit, against the one-tile-per-workgroup
-    patch kernel: plain, with BatchNorm partial sums (one slab row per workgroup), with the fused activation of a
-    BatchNorm-less layer, and with the activation-backward mask of a data-gradient launch (arrives by LDS-DMA)."""
-    dtype, Cin, Cout = G.BF16, (128 if kind == "convT" else 64), (64 if kind == "convT" else 128)
-    g = torch.Generator().manual_seed(H * 3 + B)
-    if kind == "convT":
-        x = _q(torch.randn(B, Cin, H, H, generator=g), dtype)
-        w = torch.randn(Cin, Cout, 4, 4, generator=g) * 0.1
-        ref = F.conv_transpose2d(x, _q(w, dtype), None, stride=2, padding=1)
-        gg, pk = G.convT_fprop(B, H, H, Cin, Cout, 4, 2, 1, dtype)
-        oh = 2 * H
-    else:
-        x = _q(torch.randn(B, Cout, H // 2, H // 2, generator=g), dtype)
-        w = torch.randn(Cout, Cin, 4, 4, generator=g) * 0.1
-        ref = torch.nn.grad.conv2d_input((B, Cin, H, H), _q(w, dtype), x, stride=2, padding=1)
-        gg, pk = G.conv_dgrad(B, H, H, Cin, Cout, 4, 2, 1, dtype)
-        oh = H
-    Wp = ops.pack_weights(pk, w.to(DEV), dtype)
-    X = _dev(to_nhwc(x, gg.IC), dtype, ops)
-    below = _q(torch.randn(B, 64, oh, oh, generator=g), dtype)                  # activated output of the layer below (mask operand)
-    Xm = _dev(to_nhwc(below, 64), dtype, ops)
-    M = gg.B * gg.GH * gg.GW
-    monkeypatch.setenv("VG_TILE_MIN_WGS", "1")       # small problems still take the patch kernel (same summation order)
-    outs = {}
-    for mode in ("patch", "regw"):
-        monkeypatch.setenv("VG_GG_STATIONARY", "2" if mode == "regw" else "0")
-        Y, st, nparts = ops.gather_gemm(gg, X, Wp, dtype, want_stats=True)
-        if mode == "regw":
-            assert nparts <= 512 and (M // 128) % (nparts // gg.nphase) == 0, nparts       # one slab row per workgroup
-            assert ops.gather_gemm_tile_m(gg, X, Wp, dtype) == (M // 128) // (nparts // gg.nphase) * 128
-        stats = st[: nparts * 2 * 64].view(nparts, 2, 64).double().sum(0).cpu()
-        Ya, _, _ = ops.gather_gemm(gg, X, Wp, dtype, act=(2, 0.2))
-        Ym, _, _ = ops.gather_gemm(gg, X, Wp, dtype, mask=(Xm, 2, 0.2))
-        Yp, _, _ = ops.gather_gemm(gg, X, Wp, dtype)
-        outs[mode] = (from_nhwc(Y.double().cpu(), 64), stats, Ya.cpu(), Ym.cpu(), Yp.cpu())
-    close(outs["regw"][0], ref, dtype)
-    assert torch.equal(outs["regw"][0], outs["patch"][0])            # same products in the same order (chunk, tap)
-    torch.testing.assert_close(outs["regw"][1], outs["patch"][1], rtol=1e-5, atol=1e-2)
-    for k in (2, 3, 4):
-        assert torch.equal(outs["regw"][k], outs["patch"][k]), k
-    close(from_nhwc(outs["regw"][2].double(), 64), F.leaky_relu(ref, 0.2), dtype)
-    close(from_nhwc(outs["regw"][3].double(), 64), ref * torch.where(below.double() > 0, 1.0, 0.2), dtype)
-
-
 @pytest.mark.parametrize("kind,B,H,Cin,Cout", [("conv", 8, 16, 64, 128), ("convT", 8, 8, 128, 64), ("convT", 8, 1, 100, 1024),
                                                ("conv", 3, 16, 32, 64)])
-def test_workgroup_order_switches_do_not_change_results(ops, monkeypatch, kind, B, H, Cin, Cout):
+def test_workgroup_order_switches_do_not_change_results(ops, vg_switch, kind, B, H, Cin, Cout):
     """The XCD-aware workgroup orders (wgrad: VG_WG_XCD, gather-GEMM: VG_GG_NMAJOR) are pure placement: forced on for
     every launch (=2) and off (=0) must give bit-identical outputs, also where the grid is not a multiple of 8."""
     dtype = G.BF16
@@ -695,8 +586,8 @@ def test_workgroup_order_switches_do_not_change_results(ops, monkeypatch, kind, 
     Wp, Wd = ops.pack_weights(pk, w, dtype), ops.pack_weights(pkd, w, dtype)
     res = {}
     for mode in ("0", "2"):
-        monkeypatch.setenv("VG_WG_XCD", mode)
-        monkeypatch.setenv("VG_GG_NMAJOR", mode)
+        vg_switch("VG_WG_XCD", mode)
+        vg_switch("VG_GG_NMAJOR", mode)
         Y, _, _ = ops.gather_gemm(gg, X, Wp, dtype)
         DX, _, _ = ops.gather_gemm(ggd, DY, Wd, dtype)
         dW = torch.zeros(w.shape, device=DEV)
@@ -708,7 +599,7 @@ def test_workgroup_order_switches_do_not_change_results(ops, monkeypatch, kind, 
 
 
 @pytest.mark.parametrize("rpg,C,groups,act,slope", [(2048, 512, 2, 2, 0.2), (4096, 256, 1, 1, 0.0), (512, 1024, 1, 1, 0.0), (4608, 128, 1, 2, 0.01)])
-def test_bn_finalize_and_forward_in_one_launch(ops, monkeypatch, rpg, C, groups, act, slope):
+def test_bn_finalize_and_forward_in_one_launch(ops, vg_switch, rpg, C, groups, act, slope):
     """bf16 train-mode BatchNorm with a small statistics slab: vg_bn_finalize_act_forward (every workgroup re-derives its
     64 channels' coefficients) against vg_bn_finalize_grouped + vg_bn_act_forward -- coefficients, running statistics
     (updated group after group) and the activated output."""
@@ -744,13 +635,13 @@ def test_bn_finalize_and_forward_in_one_launch(ops, monkeypatch, rpg, C, groups,
         z = F.batch_norm(xs, None, None, gamma.double().cpu(), beta.double().cpu(), True, 0.1, 1e-5)
         ref = (F.leaky_relu(z, slope) if act == 2 else F.relu(z)).view(rpg, C)
         torch.testing.assert_close(y2[k * rpg:(k + 1) * rpg].double().cpu(), ref, **TOL[dt])
-    monkeypatch.setenv("VG_BN_FUSED_FWD", "0")
+    vg_switch("VG_BN_FUSED_FWD", "0")
     assert ops.bn_finalize_act_forward(x, stats, nparts, C, rows, gamma, beta, rm2, rv2, 0.1, 1e-5, act, slope, dt, groups=groups) is None
     assert ops.bn_finalize_act_forward(x.float(), stats, nparts, C, rows, gamma, beta, rm2, rv2, 0.1, 1e-5, act, slope, G.F32, groups=groups) is None
 
 
 @pytest.mark.parametrize("rpg,C,groups,act,slope", [(2048, 512, 2, 2, 0.2), (4096, 256, 1, 1, 0.0), (4608, 128, 1, 2, 0.01)])
-def test_bn_backward_finalize_and_apply_in_one_launch(ops, monkeypatch, rpg, C, groups, act, slope):
+def test_bn_backward_finalize_and_apply_in_one_launch(ops, vg_switch, rpg, C, groups, act, slope):
     """bf16 BatchNorm backward of a small layer: vg_bn_backward_finalize_apply (through ops.bn_act_backward) against the
     grouped finalize + apply it replaces (VG_BN_FUSED_FWD=0): dx, and dgamma / dbeta accumulated onto old values in
     group order."""
@@ -769,7 +660,7 @@ def test_bn_backward_finalize_and_apply_in_one_launch(ops, monkeypatch, rpg, C, 
     seed_g, seed_b = torch.randn(C, generator=g).to(DEV), torch.randn(C, generator=g).to(DEV)
     out = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("VG_BN_FUSED_FWD", mode)
+        vg_switch("VG_BN_FUSED_FWD", mode)
         dg, db = seed_g.clone(), seed_b.clone()
         dx = ops.bn_act_backward(x, dy, co, rows, C, rows, gamma, act, slope, dg, db, True, dt)
         out[mode] = (dx, dg, db)
@@ -784,127 +675,6 @@ def test_bn_backward_finalize_and_apply_in_one_launch(ops, monkeypatch, rpg, C, 
     a = F.leaky_relu(z, slope) if act == 2 else F.relu(z)
     (dx_ref,) = torch.autograd.grad(a, xr, dy[:rpg].double().cpu().view(rpg, C, 1, 1))
     torch.testing.assert_close(out["1"][0][:rpg].double().cpu(), dx_ref.view(rpg, C), rtol=5e-2, atol=5e-2)
-
-
-BNB_CASES = [  # kind, B, H, Cin, Cout, act, slope: data-gradient launches whose output lands under a BatchNorm layer
-    ("convT_dgrad", 8, 16, 128, 128, 1, 0.0), ("convT_dgrad", 16, 4, 256, 512, 1, 0.0), ("convT_dgrad", 4, 8, 160, 64, 1, 0.0),
-    ("conv_dgrad", 8, 32, 128, 256, 2, 0.2), ("conv_dgrad", 8, 32, 64, 128, 2, 0.2), ("conv_dgrad", 4, 64, 32, 64, 2, 0.2),
-    ("convT3_dgrad", 4, 32, 64, 3, 1, 0.0), ("convT3_dgrad", 2, 64, 32, 3, 1, 0.0),          # narrow-K kernel (G5's dgrad)
-]
-
-
-@pytest.mark.parametrize("kind,B,H,Cin,Cout,act,slope", BNB_CASES)
-def test_data_gradient_epilogue_emits_the_batchnorm_backward_sums(ops, monkeypatch, kind, B, H, Cin, Cout, act, slope):
-    """vg_gg_desc.bnb_*: the slabs a data-gradient launch writes, summed over their rows, against the column sums
-    vg_bn_act_backward_reduce produces from the same (stored, rounded) gradient; the gradient itself is untouched; and
-    ops.bn_act_backward(partial=...) gives the dx / dgamma / dbeta of the three-pass form."""
-    dt = G.BF16
-    g = torch.Generator().manual_seed(H * 5 + Cin)
-    if kind == "conv_dgrad":
-        dy = _q(torch.randn(B, Cout, H // 2, H // 2, generator=g), dt)
-        w = torch.randn(Cout, Cin, 4, 4, generator=g) * 0.1
-        gg, pk = G.conv_dgrad(B, H, H, Cin, Cout, 4, 2, 1, dt)
-    elif kind == "convT_dgrad":
-        dy = _q(torch.randn(B, Cout, 2 * H, 2 * H, generator=g), dt)
-        w = torch.randn(Cin, Cout, 4, 4, generator=g) * 0.1
-        gg, pk = G.convT_dgrad(B, H, H, Cin, Cout, 4, 2, 1, dt)
-    else:                                            # ConvTranspose2d(Cin -> 3, k3 s1 p1): the Generator's last layer
-        dy = _q(torch.randn(B, Cout, H, H, generator=g), dt)
-        w = torch.randn(Cin, Cout, 3, 3, generator=g) * 0.1
-        gg, pk = G.convT_dgrad(B, H, H, Cin, Cout, 3, 1, 1, dt)
-    Wp = ops.pack_weights(pk, w.to(DEV), dt)
-    X = _dev(to_nhwc(dy, gg.IC), dt, ops)
-    monkeypatch.setenv("VG_TILE_MIN_WGS", "1")
-    monkeypatch.setenv("VG_SPLITK_MAX_TILES", "0")   # (split-K, which these small problems would take, has no epilogue)
-    nparts = ops.gather_gemm_bnb_parts(gg, X, Wp, dt)
-    assert nparts > 0, "this shape is expected on a kernel with the epilogue"
-    rows, C = B * H * H, Cin
-    y = (torch.randn(rows, C, generator=g) * 1.3 + 0.2).to(DEV).to(torch.bfloat16)          # raw output of the layer below
-    gamma = (torch.randn(C, generator=g) * 0.1 + 1).to(DEV)
-    beta = (torch.randn(C, generator=g) * 0.1).to(DEV)
-    mean, var = y.float().mean(0), y.float().var(0, unbiased=False)
-    invstd = 1.0 / torch.sqrt(var + 1e-5)
-    scale = gamma * invstd
-    co = torch.stack([mean, invstd, scale, beta - mean * scale]).unsqueeze(0).contiguous()
-    D0, _, _ = ops.gather_gemm(gg, X, Wp, dt)
-    D0 = D0.clone()
-    D1, slab, n = ops.gather_gemm(gg, X, Wp, dt, bnb=(y.view(D0.shape), co[0], act, slope))
-    assert n == nparts and torch.equal(D0, D1)
-    got = slab[: n * 2 * C].view(n, 2, C).double().sum(0).cpu()
-    # the reduce pass on the same stored gradient
-    yf, df = y.double().cpu(), D1.reshape(rows, C).double().cpu()
-    z = scale.double().cpu() * yf + (beta - mean * scale).double().cpu()
-    dz = df * torch.where(z > 0, torch.ones_like(z), torch.full_like(z, slope if act == 2 else 0.0))
-    xhat = (yf - mean.double().cpu()) * invstd.double().cpu()
-    want = torch.stack([dz.sum(0), (dz * xhat).sum(0)])
-    tol = 2e-5 * torch.stack([dz.abs().sum(0), (dz * xhat).abs().sum(0)]) + 1e-6
-    assert bool(((got - want).abs() <= tol).all()), float(((got - want).abs() / tol).max())
-    # and through the BatchNorm backward
-    out = {}
-    for mode in ("three", "partial"):
-        dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
-        if mode == "partial":
-            _, slab, n = ops.gather_gemm(gg, X, Wp, dt, bnb=(y.view(D0.shape), co[0], act, slope))
-        dx = ops.bn_act_backward(y, D1.reshape(rows, C), co, rows, C, rows, gamma, act, slope, dg, db, False, dt,
-                                 partial=(slab, n) if mode == "partial" else None)
-        out[mode] = (dx.clone(), dg, db)
-    torch.cuda.synchronize()
-    torch.testing.assert_close(out["partial"][1], out["three"][1], rtol=2e-5, atol=2e-4 * float(out["three"][1].abs().max()))
-    torch.testing.assert_close(out["partial"][2], out["three"][2], rtol=2e-5, atol=2e-4 * float(out["three"][2].abs().max()))
-    d = (out["partial"][0].float() - out["three"][0].float()).abs()
-    assert float(d.max()) <= 2.0 ** -7 * float(out["three"][0].float().abs().max()) and float((d > 0).float().mean()) < 1e-3
-
-
-def test_batchnorm_backward_epilogue_is_refused_where_no_kernel_has_it(ops):
-    """A descriptor on a kernel without the epilogue (f32) probes 0 and the launch is refused rather than silently skipped."""
-    gg, pk = G.convT_dgrad(4, 8, 8, 64, 64, 4, 2, 1, G.F32)
-    X = torch.zeros(4, 16, 16, gg.IC, device=DEV)
-    w = torch.zeros(64, 64, 4, 4, device=DEV)
-    Wp = ops.pack_weights(pk, w, G.F32)
-    assert ops.gather_gemm_bnb_parts(gg, X, Wp, G.F32) == 0
-    with pytest.raises(RuntimeError):
-        ops.gather_gemm(gg, X, Wp, G.F32, bnb=(torch.zeros(4, 8, 8, 64, device=DEV), torch.zeros(4, 64, device=DEV), 1, 0.0))
-
-
-def test_edge_kernels_apply_the_batchnorm_of_the_layer_below_on_their_loads(ops):
-    """vg_tnconv / vg_edge_wgrad input prologue: fed the RAW output of the layer below plus its BatchNorm scale / shift
-    and activation, they must give bit for bit what they give on the tensor vg_bn_act_forward stores."""
-    dt = G.BF16
-    B, H, C, N = 4, 64, 64, 3
-    g = torch.Generator().manual_seed(11)
-    y = (torch.randn(B, H, H, C, generator=g) * 1.2 + 0.3).to(DEV).to(torch.bfloat16)
-    scale = (torch.rand(C, generator=g) + 0.5).to(DEV)
-    shift = (torch.randn(C, generator=g) * 0.3).to(DEV)
-    co = torch.stack([torch.zeros(C, device=DEV), torch.ones(C, device=DEV), scale, shift]).unsqueeze(0).contiguous()
-    a = ops.bn_act_forward(y, co, B * H * H, C, 1, 0.0, dt)                       # ReLU, as the Generator's blocks
-    tn, pk = G.convT_fprop_tn(B, H, H, C, N, 3, 1, 1, dt)
-    w = torch.randn(C, N, 3, 3, generator=g).to(DEV) * 0.1
-    Wp = ops.pack_weights(pk, w, dt)
-    Y1, I1 = ops.tnconv(tn, a, Wp, want_nchw=True, act=3)
-    Y2, I2 = ops.tnconv(tn, y, Wp, want_nchw=True, act=3, pre=(scale, shift, 1, 0.0))
-    assert torch.equal(Y1, Y2) and torch.equal(I1, I2)
-    ew = G.convT_wgrad_edge(B, H, H, C, N, 3, 1, 1, dt)
-    dimg = torch.randn(B, H, H, 8, generator=g).to(DEV).to(torch.bfloat16)
-    dimg[..., N:] = 0
-    d1, d2 = torch.zeros_like(w), torch.zeros_like(w)
-    ops.edge_wgrad(ew, a, dimg, d1, False)
-    ops.edge_wgrad(ew, y, dimg, d2, False, pre=(scale, shift, 1, 0.0))
-    assert torch.equal(d1, d2)
-    # LeakyReLU prologue and a 32-channel wide operand
-    C2 = 32
-    y2 = torch.randn(B, H, H, C2, generator=g).to(DEV).to(torch.bfloat16)
-    sc2, sh2 = (torch.rand(C2, generator=g) + 0.5).to(DEV), (torch.randn(C2, generator=g) * 0.3).to(DEV)
-    co2 = torch.stack([torch.zeros(C2, device=DEV), torch.ones(C2, device=DEV), sc2, sh2]).unsqueeze(0).contiguous()
-    a2 = ops.bn_act_forward(y2, co2, B * H * H, C2, 2, 0.2, dt)
-    tn2, pk2 = G.convT_fprop_tn(B, H, H, C2, N, 3, 1, 1, dt)
-    w2 = torch.randn(C2, N, 3, 3, generator=g).to(DEV) * 0.1
-    Wp2 = ops.pack_weights(pk2, w2, dt)
-    assert torch.equal(ops.tnconv(tn2, a2, Wp2)[0], ops.tnconv(tn2, y2, Wp2, pre=(sc2, sh2, 2, 0.2))[0])
-    ew2 = G.convT_wgrad_edge(B, H, H, C2, N, 3, 1, 1, dt)
-    e1, e2 = torch.zeros_like(w2), torch.zeros_like(w2)
-    ops.edge_wgrad(ew2, a2, dimg, e1, False)
-    ops.edge_wgrad(ew2, y2, dimg, e2, False, pre=(sc2, sh2, 2, 0.2))
-    assert torch.equal(e1, e2)
 
 
 @pytest.mark.parametrize("B", [1, 37, 128, 300])

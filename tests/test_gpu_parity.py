@@ -58,6 +58,23 @@ def later_step_tol(ref32, ref64):
     return max(1.0, 4 * rel(ref32, ref64))
 
 
+def oracle_twin_fp64(o):
+    """An fp64 copy of the oracle in its CURRENT state (parameters, BatchNorm buffers, Adam moments and step counts):
+    running the same step on both measures how far the reference's fp32 arithmetic itself is from exact."""
+    t = R.RefVAEGAN(img_size=o.img_size, latent_dim=o.latent_dim, lr=o.opt_E.lr, seed=None).double_()
+    for src, dst in ((o.E, t.E), (o.G, t.G), (o.D, t.D)):
+        for k, v in src.items():
+            with torch.no_grad():
+                dst[k].copy_(v.detach())
+    for so, do in ((o.opt_E, t.opt_E), (o.opt_G, t.opt_G), (o.opt_D, t.opt_D)):
+        do.t = so.t
+        for a, b in zip(do.exp_avg, so.exp_avg):
+            a.copy_(b)
+        for a, b in zip(do.exp_avg_sq, so.exp_avg_sq):
+            a.copy_(b)
+    return t
+
+
 def sync_from_oracle(o, e, g, d, tr):
     """Teacher forcing: copy the oracle's parameters, BN buffers and Adam state into the HIP model."""
     for m, st in ((e, o.E), (g, o.G), (d, o.D)):
@@ -133,7 +150,9 @@ def test_generator_discriminator_forward_kat_vs_reference_golden(golden_dir):
 MOMENT_TOL, BUFFER_TOL, FLIP_FRAC = 2e-2, 2e-3, 0.05
 
 
-def check_state_after_first_iteration(gold, e, g, d, tr, o64=None, lr=2e-4):
+def check_state_after_first_iteration(gold, e, g, d, tr, o64=None, lr=2e-4, tols=None):
+    """tols = (moment, buffer, flip fraction) overrides the fp32 bounds above (the bf16 engine states its own)."""
+    MOMENT_TOL, BUFFER_TOL, FLIP_FRAC = tols if tols is not None else (globals()["MOMENT_TOL"], globals()["BUFFER_TOL"], globals()["FLIP_FRAC"])
     worst = {"moment": 0.0, "buffer": 0.0, "param_flip": 0.0}
     ref64 = {} if o64 is None else {"E": o64.opt_E, "G": o64.opt_G, "D": o64.opt_D}
     for name, m, opt in (("E", e, tr.opt_E), ("G", g, tr.opt_G), ("D", d, tr.opt_D)):
@@ -184,11 +203,15 @@ def check_state_after_first_iteration(gold, e, g, d, tr, o64=None, lr=2e-4):
                     continue
                 err = dist(got, ref)
                 worst["moment"] = max(worst["moment"], err)
+                worst[mom] = max(worst.get(mom, 0.0), err)
+                if err == worst[mom]:
+                    worst[mom + "_at"] = f"{name}.{pnames[i]}"
                 tol = MOMENT_TOL if mom == "exp_avg" else 2.5 * MOMENT_TOL      # second moment: quadratic in the gradient
                 tol = max(tol, 4 * cal[mom])
                 assert err <= tol, (f"after iteration 1: Adam {name} param {i} ({pnames[i]}) {mom} checksum differs by "
                                     f"{err:.2e} (tol {tol:.1e}; reference fp32 vs fp64: {cal[mom]:.1e})")
-    print("after-iteration-1 state vs reference checksums, worst:", {k: f"{v:.2e}" for k, v in worst.items()})
+    print("after-iteration-1 state vs reference checksums, worst:", {k: (v if isinstance(v, str) else f"{v:.2e}") for k, v in worst.items()})
+    return worst
 
 # --------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("B,epoch", [(2, 25), (2, 60), (4, 0)])
@@ -261,10 +284,13 @@ def test_teacher_forced_steps_adam_and_batchnorm_state(S, B):
     t > 1, non-trivial running statistics and momentum history are checked without chaotic compounding."""
     e, g, d, tr = build(S)
     o = R.RefVAEGAN(img_size=S, seed=42)
+    worst_moment = 0.0
     for step in range(3):
         sync_from_oracle(o, e, g, d, tr)
         before_all = {id(st): {k: v.detach().clone() for k, v in st.items()} for st in (o.E, o.G, o.D)}
         real, ez, er, ec = make_inputs(B, S, 9000 + S + step)
+        o64 = oracle_twin_fp64(o)
+        o64.train_step(real, ez, er, ec, 25)
         ref = o.train_step(real, ez, er, ec, 25)
         got = tr.loss_dict(tr.train_step(real.to(DEV), 25, ez.to(DEV), er.to(DEV), ec.to(DEV)), 25)
         for n in V.LOSS_NAMES:
@@ -272,16 +298,27 @@ def test_teacher_forced_steps_adam_and_batchnorm_state(S, B):
         for m, st, opt, ro in ((e, o.E, tr.opt_E, o.opt_E), (g, o.G, tr.opt_G, o.opt_G), (d, o.D, tr.opt_D, o.opt_D)):
             assert float(opt.state_dev[0]) == ro.t
             before = before_all[id(st)]
-            # Adam moments are linear / quadratic in the gradients: bounded like the gradients themselves (the
-            # worst generator gradients carry up to 1e-1 of their max as fp32 error in the reference too, see
-            # test_all_parameter_gradients_vs_fp64_oracle)
-            m_ref = torch.cat([t.flatten() for t in ro.exp_avg]).double()
-            v_ref = torch.cat([t.flatten() for t in ro.exp_avg_sq]).double()
+            # Adam moments, PER TENSOR, in the calibration of check_state_after_first_iteration: relative Frobenius
+            # distance from the CPU-fp32 oracle <= max(MOMENT_TOL (2.5x for the quadratic second moment), 4 x the
+            # distance of that oracle from an fp64 run of the SAME step from the SAME state) -- the fp64 twin is a copy
+            # of the oracle taken before the step (the worst generator gradients carry up to 1e-1 of their size as fp32
+            # error in the reference too, test_all_parameter_gradients_vs_fp64_oracle).  Round 2 held the concatenation
+            # of all tensors to a flat 15 % of its max.
+            ro64 = {id(o.opt_E): o64.opt_E, id(o.opt_G): o64.opt_G, id(o.opt_D): o64.opt_D}[id(ro)]
             hsd = opt.state_dict()["state"]
-            m_hip = torch.cat([hsd[i]["exp_avg"].flatten() for i in range(len(ro.params))]).double().cpu()
-            v_hip = torch.cat([hsd[i]["exp_avg_sq"].flatten() for i in range(len(ro.params))]).double().cpu()
-            assert float((m_hip - m_ref).abs().max() / m_ref.abs().max()) <= 1.5e-1
-            assert float((v_hip - v_ref).abs().max() / v_ref.abs().max()) <= 1.5e-1
+            pk = R.trainable_keys(st)
+            for i in range(len(ro.params)):
+                if pk[i].endswith("conv.bias") and m is e:
+                    continue                    # exactly-zero true gradient: rounding noise in every implementation
+                for mom, base in (("exp_avg", MOMENT_TOL), ("exp_avg_sq", 2.5 * MOMENT_TOL)):
+                    r32, r64 = getattr(ro, mom)[i].double(), getattr(ro64, mom)[i].double()
+                    if float(r32.norm()) == 0.0:
+                        continue
+                    cal = float((r32 - r64).norm() / r32.norm())
+                    err = float((hsd[i][mom].double().cpu() - r32).norm() / r32.norm())
+                    worst_moment = max(worst_moment, err)
+                    assert err <= max(base, 4 * cal), (f"forced step {step} {pk[i]} {mom}: {err:.2e} from the fp32 oracle "
+                                                       f"(its own distance from fp64: {cal:.1e})")
             for k, v in m.state_dict().items():
                 r = st[k].detach()
                 if k.endswith("num_batches_tracked"):
@@ -300,6 +337,7 @@ def test_teacher_forced_steps_adam_and_batchnorm_state(S, B):
                     err = ((v.cpu() - before[k]).double() - (r - before[k]).double()).abs() / 2e-4
                     assert float(err.median()) <= 0.02 and float(err.mean()) <= 0.25, \
                         f"step {step} {k}: median/mean update error {float(err.median()):.3f}/{float(err.mean()):.3f} lr"
+    print(f"teacher-forced S={S} B={B}: worst per-tensor Adam-moment distance from the fp32 oracle {worst_moment:.2e}")
 
 
 def _grads_step(S, B, dtype="fp32"):
@@ -384,7 +422,9 @@ def test_benchmarked_configurations_replayed_graph_vs_oracle(S, B, dtype):
     assert tr._graph is graph, "the restored state must replay the captured graph, not re-capture"
     ref = o.train_step(real, ez, er, ec, 60)
     for n in V.LOSS_NAMES + ("total",):
-        tol = FIRST_STEP_TOL[n] if dtype == "fp32" else 3e-2          # bf16: stated tolerance of the bf16 path
+        # fp32 at the benchmarked batch: EVERY loss inside north_star's 1e-4, also the two evaluated after Adam(t=1)
+        # updates of D (measured <= 2.1e-5; the looser FIRST_STEP_TOL entries are for the B = 2..4 fixtures)
+        tol = 1e-4 if dtype == "fp32" else 3e-2                       # bf16: stated tolerance of the bf16 path
         assert rel(got[n], ref[n]) <= tol, f"S={S} B={B} {dtype} replay {n}: hip {got[n]} oracle {ref[n]} (tol {tol:.0e})"
         assert got[n] == eager[n], f"replayed graph differs from the eager iteration in {n}: {got[n]} vs {eager[n]}"
     print(f"S={S} B={B} {dtype}:", {n: f"{rel(got[n], ref[n]):.1e}" for n in V.LOSS_NAMES})
@@ -830,6 +870,35 @@ def test_checkpoint_resume_is_bitwise_identical(tmp_path, graphed):
     assert tr.opt_D.steps == 8 and tr.opt_E.steps == 4
 
 
+@pytest.mark.parametrize("graphed", [False, True])
+def test_checkpoint_resume_continues_the_device_noise_stream(tmp_path, graphed):
+    """round-2 ADVICE: resume with the in-kernel randn draws (eps=None).  The checkpoint carries the noise stream's
+    {seed, iteration}; a resuming process that is seeded DIFFERENTLY (or not at all) must continue that stream, not
+    restart one from its own seed at iteration 0 -- only an explicit re-seed after the restore starts a new stream."""
+    S, B = 64, 4
+    real = [make_inputs(B, S, 710 + i)[0].to(DEV) for i in range(4)]
+
+    def run(tr, idx):
+        fn = tr.train_step_graphed if graphed else tr.train_step
+        return [fn(real[i], 60)[:5].clone() for i in idx]
+
+    e, g, d, tr = build(S)
+    torch.cuda.manual_seed(555)
+    run(tr, [0, 1])
+    path = str(tmp_path / "ck_noise.pth")
+    tr.save_checkpoint(path)
+    la = run(tr, [2, 3])
+    e2, g2, d2, tr2 = build(S)
+    torch.cuda.manual_seed(99)                          # the resuming process has another device seed
+    tr2.load_checkpoint(path)
+    lb = run(tr2, [2, 3])
+    for a, b in zip(la, lb):
+        assert torch.equal(a, b)
+    torch.cuda.manual_seed(1234)                        # an explicit re-seed AFTER the restore does start a new stream
+    lc = run(tr2, [2])
+    assert tr2.noise.seed == 1234 and not torch.equal(lc[0], la[0])
+
+
 @pytest.mark.parametrize("S,sigma", [(64, 0.2), (64, 0.05), (128, 0.2)])
 def test_denoise_eval_path_vs_oracle(S, sigma):
     """BASELINE config 4 / vaegan_code.py:147-171: eval-mode E -> reparam -> G on clamp(img + sigma*eps, -1, 1),
@@ -851,67 +920,6 @@ def test_denoise_eval_path_vs_oracle(S, sigma):
     a01, b01 = (recon_ref + 1) / 2, (img + 1) / 2
     assert abs(out["psnr"] - R.psnr(a01, b01)) < 1e-3
     assert abs(out["ssim"] - R.ssim(a01, b01)) < 1e-4
-
-
-def test_edge_prologue_training_iteration_equals_default(monkeypatch):
-    """VG_EDGE_PROLOGUE=1 (the last Generator block's BatchNorm + ReLU applied inside the edge kernels' operand loads, no
-    activated copy) must leave a bf16 training iteration bit-identical: the prologue produces exactly the stored values."""
-    outs = []
-    for mode in ("0", "1"):
-        monkeypatch.setenv("VG_EDGE_PROLOGUE", mode)
-        V.configure_seed(42)
-        e, g, d, tr = build(64, dtype="bf16")
-        x = torch.randn(8, 3, 64, 64, generator=torch.Generator().manual_seed(3)).clamp(-1, 1).to(DEV)
-        l1 = tr.train_step(x, 60)[:5].clone()
-        l2 = tr.train_step(x, 60)[:5].clone()
-        torch.cuda.synchronize()
-        outs.append(torch.stack([l1, l2]).cpu())
-    assert torch.equal(outs[0], outs[1])
-
-
-def test_batchnorm_backward_sums_in_the_data_gradient_epilogue_train_like_the_default(monkeypatch):
-    """VG_BNB=1 (stage i+1's data-gradient launch emits the BatchNorm-backward partial sums of stage i; no reduce pass):
-    the sums are the same numbers added in another order, so two bf16 training iterations agree to f32 rounding of the
-    BatchNorm parameter gradients -- losses after one step identical to 5e-3 relative."""
-    outs, kernels = [], []
-    for mode in ("0", "1"):
-        monkeypatch.setenv("VG_BNB", mode)
-        V.configure_seed(42)
-        e, g, d, tr = build(64, dtype="bf16")
-        assert g._engine.bnb_epilogue == (mode == "1")
-        x = torch.randn(8, 3, 64, 64, generator=torch.Generator().manual_seed(3)).clamp(-1, 1).to(DEV)
-        l1 = tr.train_step(x, 60)[:5].clone()
-        l2 = tr.train_step(x, 60)[:5].clone()
-        torch.cuda.synchronize()
-        outs.append(torch.stack([l1, l2]).cpu())
-        kernels.append(sum(p.detach().double().sum().item() for p in g.parameters()))
-    assert torch.equal(outs[0][0], outs[1][0])                       # the first iteration's losses precede any update
-    torch.testing.assert_close(outs[1][1], outs[0][1], rtol=5e-3, atol=1e-3)
-    assert abs(kernels[0] - kernels[1]) <= 1e-3 * abs(kernels[0]) + 1e-3
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("graphed", [False, True])
-def test_side_stream_schedule_leaves_the_iteration_bit_identical(monkeypatch, graphed):
-    """VG_OVERLAP=3 (the Generator's Adam step + operand re-pack and the dead Discriminator
-    weight gradients beside the Encoder's backward, on the side stream / as a side graph) only reorders independent launches: three bf16
-    training iterations leave losses, every parameter and every Adam moment bit-identical to the serial schedule."""
-    outs = []
-    for mode in ("0", "3"):
-        monkeypatch.setenv("VG_OVERLAP", mode)
-        V.configure_seed(42)
-        e, g, d, tr = build(64, dtype="bf16")
-        assert tr.overlap == int(mode)
-        x = torch.randn(8, 3, 64, 64, generator=torch.Generator().manual_seed(3)).clamp(-1, 1).to(DEV)
-        step = tr.train_step_graphed if graphed else tr.train_step
-        ls = [step(x, 60)[:5].clone() for _ in range(3)]
-        torch.cuda.synchronize()
-        state = [torch.stack(ls).cpu()]
-        for o in (tr.opt_E, tr.opt_G, tr.opt_D):
-            state += [o.flat_p.cpu().clone(), o.exp_avg.cpu().clone(), o.exp_avg_sq.cpu().clone(), o.flat_g.cpu().clone()]
-        outs.append(state)
-    for a, b in zip(outs[0], outs[1]):
-        assert torch.equal(a, b)
 
 
 @pytest.mark.gpu

@@ -231,3 +231,28 @@ def test_bf16_siblings_track_fp32_oracle():
     got = tr.train_step(img.to(DEV), noises[0].to(DEV)).tolist()
     for i, n in enumerate(("errD_real", "errD_fake", "errG")):
         assert rel(got[i], lo[n]) <= 3e-2, (n, got[i], lo[n])
+
+
+def test_sibling_graph_is_recaptured_after_a_reseed():
+    """round-2 ADVICE: the captured vg_rng_advance / vg_randn launches hold the raw pointer of the default noise stream's
+    state; utils.configure_seed() drops that stream (ops.reset_noise).  The replay after a reseed must neither write
+    into the freed buffer nor ignore the new seed: the state's address is part of the capture key and the trainer keeps
+    the stream it captured alive.  Device-drawn noise, graphed == eager bit for bit across the reseed."""
+    B, S = 8, 64
+    res = []
+    for graphed in (False, True):
+        e, g, tr = build_vae(S)
+        img = sib_inputs(B, S, 0)[0].to(DEV)
+        fn = tr.step_graphed if graphed else tr.train_step
+        seq = [fn(img, None, None, epoch=60).clone() for _ in range(3)]
+        if graphed:
+            assert tr._gstate is not None
+            old_graph, old_ptr = tr._gstate[1], tr._gstate[0][-1]
+        V.configure_seed(7)                                   # new device seed: the default stream is dropped
+        seq += [fn(img, None, None, epoch=60).clone() for _ in range(3)]
+        if graphed:
+            assert tr._gstate[1] is not old_graph and tr._gstate[0][-1] != old_ptr, "reseed must re-capture"
+        torch.cuda.synchronize()
+        res.append(torch.stack(seq).cpu())
+    assert torch.equal(res[0], res[1])
+    assert not torch.equal(res[0][2], res[0][3])

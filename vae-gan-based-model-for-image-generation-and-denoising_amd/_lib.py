@@ -16,7 +16,7 @@ VG_F32, VG_BF16, VG_FP8 = 0, 1, 2
 VG_FP8_WSHIFT = 6
 VG_ACT_NONE, VG_ACT_RELU, VG_ACT_LRELU, VG_ACT_TANH = 0, 1, 2, 3
 VG_MAX_PHASE = 4
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _ERR = {-1: "VG_EINVAL (bad shape/size/flag)", -2: "VG_EALIGN (16-byte contract violated)",
         -3: "VG_ENOSUP (unsupported configuration)"}
@@ -36,9 +36,7 @@ class GGDesc(Structure):
                 ("ooy", _I4), ("oox", _I4),
                 ("nphase", c_int32), ("stats_capacity", c_int32), ("ws", c_void_p), ("ws_bytes", c_int64), ("zeros", c_void_p),
                 ("act", c_int32), ("act_slope", c_float),
-                ("mask_x", c_void_p), ("mask_act", c_int32), ("mask_slope", c_float),
-                ("bnb_y", c_void_p), ("bnb_coeffs", c_void_p), ("bnb_partial", c_void_p), ("bnb_act", c_int32),
-                ("bnb_slope", c_float), ("bnb_capacity", c_int32)]
+                ("mask_x", c_void_p), ("mask_act", c_int32), ("mask_slope", c_float)]
 
 
 class WGDesc(Structure):
@@ -57,8 +55,7 @@ class TNDesc(Structure):
                 ("rng", c_void_p), ("draw", c_int32), ("sigma", c_float),
                 ("B", c_int32), ("IH", c_int32), ("IW", c_int32), ("C", c_int32), ("N", c_int32), ("K", c_int32),
                 ("S", c_int32), ("P", c_int32), ("OH", c_int32), ("OW", c_int32), ("OC", c_int32),
-                ("Wpitch", c_int32), ("act", c_int32),
-                ("in_scale", c_void_p), ("in_shift", c_void_p), ("in_act", c_int32), ("in_slope", c_float)]
+                ("Wpitch", c_int32), ("act", c_int32)]
 
 
 class EWDesc(Structure):
@@ -67,8 +64,7 @@ class EWDesc(Structure):
                 ("zeros", c_void_p),
                 ("B", c_int32), ("WH", c_int32), ("WW", c_int32), ("C", c_int32), ("NH", c_int32), ("NW", c_int32),
                 ("N", c_int32), ("K", c_int32), ("S", c_int32), ("P", c_int32), ("s_c", c_int32), ("s_n", c_int32),
-                ("accumulate", c_int32),
-                ("in_scale", c_void_p), ("in_shift", c_void_p), ("in_act", c_int32), ("in_slope", c_float)]
+                ("accumulate", c_int32)]
 
 
 class PackDesc(Structure):
@@ -85,11 +81,11 @@ class PackDesc(Structure):
 _P, _F, _I, _L, _D = c_void_p, c_float, c_int, c_int64, c_double
 SIGNATURES = {
     "vg_abi_version": (c_int, []),
+    "vg_reload_switches": (c_int, []),
     "vg_build_info": (c_char_p, []),
     "vg_timing_enable": (c_int, [_I]),
     "vg_timing_collect": (c_int, [_I, POINTER(c_double), POINTER(c_int)]),
     "vg_gather_gemm_nparts": (c_int, [POINTER(GGDesc), _I]),
-    "vg_gather_gemm_bnb_nparts": (c_int, [POINTER(GGDesc), _I]),
     "vg_gather_gemm_tile_m": (c_int, [POINTER(GGDesc), _I]),
     "vg_gather_gemm_family": (c_int, [POINTER(GGDesc), _I]),
     "vg_gather_gemm_ws_bytes": (c_int64, [POINTER(GGDesc), _I]),

@@ -494,8 +494,7 @@ __global__ __launch_bounds__(FF_TH) void bn_fin_act_fwd_kernel(
 }
 
 inline bool bn_fin_fwd_ok(int nparts_per_group, int groups, int C, int64_t rows, int dtype) {
-    const char* e = getenv("VG_BN_FUSED_FWD");                  // read per call: tests flip it
-    const int mode = e ? atoi(e) : 1;
+    const int mode = vg_sw().bn_fused_fwd;
     // measured per shape (tools/bn_fwd_bench.py, S=64 B=128): wins 1-3 us per layer up to 8.4 MB / 196 slab rows
     // (G0 7.2 -> 4.5, D3 6.2 -> 4.3, E3 5.5 -> 3.8 us), loses beyond (G2 16.8 MB 13.4 -> 15.0, D1 256 slab rows 9.1 -> 11.4)
     return mode != 0 && dtype == VG_BF16 && C % FF_CH == 0 && groups >= 1 && rows % groups == 0 &&

@@ -130,3 +130,28 @@ inline void vg_launch_timed(int family, K kernel, dim3 grid, dim3 block, size_t 
     }
     hipExtLaunchKernelGGL(kernel, grid, block, shm, s, e0, e1, 0, args...);
 }
+
+// ---- runtime switches -------------------------------------------------------------------------------------------
+// Kernel-selection switches (all optional; the defaults are the measured optimum, DESIGN.md "Runtime switches").  They
+// are read from the environment ONCE, when the library is loaded; vg_reload_switches() (C ABI) re-reads them -- tests
+// and A/B scripts that flip a variable inside one process call it afterwards.  Nothing on a launch path calls getenv.
+struct VgSwitches {
+    int gg_dma;            // VG_GG_DMA            1: LDS-DMA staging in the gather-GEMM (0: register-staged kernels)
+    int tile_min_wgs;      // VG_TILE_MIN_WGS      512: workgroups a launch must offer before a larger tile is chosen
+    int gg_patch;          // VG_GG_PATCH          1: patch variant of the gather-GEMM
+    int gg_patch64;        // VG_GG_PATCH64        1: its 64-column form
+    int gg_patch32;        // VG_GG_PATCH32        1: its 32-column form
+    int gg_patch_nr3;      // VG_GG_PATCH_NR3      1: 128 x 64 patch kernel with 3 patch rounds (4 workgroups per CU)
+    int patch256_min;      // VG_PATCH256_MIN      256: least number of 256 x 128 tiles for the 8-wave patch kernel
+    int patch256x64_min;   // VG_PATCH256X64_MIN   512: same for the 256 x 64 tile
+    int splitk_max_tiles;  // VG_SPLITK_MAX_TILES  32: most output tiles for which the gather-GEMM splits K
+    int gg_nmajor;         // VG_GG_NMAJOR         1: XCD-major over n tiles where the weights are the larger operand (2: always)
+    int edge;              // VG_EDGE              1: narrow-K direct convolution for the 3-channel image layers
+    int wg_reduce_t;       // VG_WG_REDUCE_T       1: streaming transpose-reduce of the weight-gradient slabs
+    int wg_target;         // VG_WG_TARGET         512: workgroups the wgrad split-M factor aims for
+    int wg_spec;           // VG_WG_SPEC           3: wave-specialised 128 x 256 wgrad kernel (0: one role per wave)
+    int wg_dma;            // VG_WG_DMA            1: LDS-DMA staging in wgrad
+    int wg_xcd;            // VG_WG_XCD            1: XCD-aware workgroup order in wgrad (2: always)
+    int bn_fused_fwd;      // VG_BN_FUSED_FWD      1: BatchNorm finalize folded into the elementwise passes of small layers
+};
+const VgSwitches& vg_sw();

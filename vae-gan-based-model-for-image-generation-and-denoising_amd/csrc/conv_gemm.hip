@@ -679,48 +679,18 @@ inline int tiles_of(int M, int N, int bm, int bn) { return ((M + bm - 1) / bm) *
 
 // Pick the output tile: small-N layers get tall-skinny tiles (they are HBM-bound); otherwise the
 // largest tile that still fills the 256 CUs with >= ~2 workgroups each.
-inline bool use_dma() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("VG_GG_DMA");
-        v = e ? atoi(e) : 1;
-    }
-    return v != 0;
-}
+inline bool use_dma() { return vg_sw().gg_dma != 0; }            // VG_GG_DMA (common.hpp: switches are read once at load)
 
-#include "conv_stationary.hpp"
-#include "conv_regweights.hpp"
-
-inline int min_wgs() {                      // read per call (a few hundred ns): tests flip it inside one process
-    const char* e = getenv("VG_TILE_MIN_WGS");
-    return e ? atoi(e) : 512;
-}
+inline int min_wgs() { return vg_sw().tile_min_wgs; }            // VG_TILE_MIN_WGS
 
 // (a 256x128 tile -- wave tile 128x64, 152 VGPRs, one wave per SIMD -- was measured and loses on every layer)
-inline bool patch64() {                     // patch variant for the 128 x 64 tile (VG_GG_PATCH64=0 turns it off)
-    const char* e = getenv("VG_GG_PATCH64");
-    return e ? atoi(e) != 0 : true;
-}
-
-inline bool patch32() {                     // patch variant for 32-output-channel layers (S >= 128: VG_GG_PATCH32=0 turns it off)
-    const char* e = getenv("VG_GG_PATCH32");
-    return e ? atoi(e) != 0 : true;
-}
-
-inline bool patch_nr3() {                   // 128 x 64 patch kernel with 3 patch rounds (40 KB LDS: 4 workgroups per CU); per call
-    const char* e = getenv("VG_GG_PATCH_NR3");
-    return e ? atoi(e) != 0 : true;
-}
-
-inline int patch256_min() {
-    const char* e = getenv("VG_PATCH256_MIN");
-    return e ? atoi(e) : 256;               // 256 x 128 tiles where every CU gets at least one (step sweep: 128 / 192 / 256 / 384 -> 38.3 / 38.6 / 38.7 / 38.7k img/s)
-}
-
-inline int patch256x64_min() {
-    const char* e = getenv("VG_PATCH256X64_MIN");
-    return e ? atoi(e) : 512;               // G4 forward 63.9 -> 63.0 us, D1 data gradient 30.9 -> 28.4 (2B) and 17.8 -> 15.9 (B)
-}
+inline bool patch64() { return vg_sw().gg_patch64 != 0; }        // patch variant for the 128 x 64 tile (VG_GG_PATCH64)
+inline bool patch32() { return vg_sw().gg_patch32 != 0; }        // ... for 32-output-channel layers (S >= 128; VG_GG_PATCH32)
+inline bool patch_nr3() { return vg_sw().gg_patch_nr3 != 0; }    // 128 x 64 patch kernel with 3 patch rounds (40 KB LDS: 4 workgroups per CU)
+// 256 x 128 tiles where every CU gets at least one (step sweep: 128 / 192 / 256 / 384 -> 38.3 / 38.6 / 38.7 / 38.7k img/s)
+inline int patch256_min() { return vg_sw().patch256_min; }
+// 256 x 64: G4 forward 63.9 -> 63.0 us, D1 data gradient 30.9 -> 28.4 (2B) and 17.8 -> 15.9 (B)
+inline int patch256x64_min() { return vg_sw().patch256x64_min; }
 
 inline TileCfg pick_tile(const vg_gg_desc* d, bool bf16 = false, bool fp8 = false) {
     const int M = d->B * d->GH * d->GW;
@@ -785,7 +755,7 @@ inline SplitK plan_splitk(const vg_gg_desc* d, int dtype, TileCfg t) {
     const int nstages = ((d->Kp * esz) / 64 + kch - 1) / kch;
     const int gx = (M + t.bm - 1) / t.bm, gy = (d->N + t.bn - 1) / t.bn;
     const int tiles = gx * gy;
-    const int max_tiles = [] { const char* e = getenv("VG_SPLITK_MAX_TILES"); return e ? atoi(e) : 32; }();
+    const int max_tiles = vg_sw().splitk_max_tiles;
     if (tiles > max_tiles || nstages < 16) return r;
     int ks = 256 / tiles;
     if (ks > nstages / 4) ks = nstages / 4;
@@ -801,7 +771,7 @@ inline SplitK plan_splitk(const vg_gg_desc* d, int dtype, TileCfg t) {
 // 4-8 MB of activations at B = 128) dealing the n tiles instead moves 8x less weight traffic out of the Infinity
 // Cache.  VG_GG_NMAJOR=0 turns it off.
 inline bool n_major(const vg_gg_desc* d, int n_tiles, int esz) {
-    const int mode = [] { const char* e = getenv("VG_GG_NMAJOR"); return e ? atoi(e) : 1; }();        // per call: tests flip it
+    const int mode = vg_sw().gg_nmajor;
     if (mode == 0 || n_tiles % 8 != 0) return false;
     const int64_t wbytes = (int64_t)d->nphase * d->N * d->Kp * esz;
     const int64_t abytes = (int64_t)d->B * d->IH * d->IW * d->IC * esz;
@@ -858,40 +828,9 @@ int dispatch(const vg_gg_desc* d, TileCfg t, hipStream_t s, SplitK sk) {
 extern "C" int vg_gather_gemm_nparts(const vg_gg_desc* d, int dtype) {
     int rc = validate(d, dtype);
     if (rc) return rc;
-    PatchGeo pg;
-    StatPlan sp;
-    if (stationary_plan(d, dtype, &pg, &sp)) return d->nphase * sp.wgs_per_phase;     // one slab row per workgroup
-    RegwPlan rp;
-    if (regw_plan(d, dtype, &pg, &rp)) return d->nphase * rp.wgs_per_phase;
     TileCfg t = pick_tile(d, dtype == VG_BF16, dtype == VG_FP8);
     const int M = d->B * d->GH * d->GW;
     return d->nphase * ((M + t.bm - 1) / t.bm);
-}
-
-namespace {
-// rows of bnb_partial a launch writes (0: the kernel this descriptor runs on has no BatchNorm-backward epilogue)
-inline int bnb_parts(const vg_gg_desc* d, int dtype) {
-    if (dtype != VG_BF16) return 0;
-    PatchGeo pg;
-    StatPlan sp;
-    if (stationary_plan(d, dtype, &pg, &sp)) return 0;
-    RegwPlan rp;
-    if (regw_plan(d, dtype, &pg, &rp)) return 0;
-    const int M = d->B * d->GH * d->GW;
-    if (narrowk_ok(d, dtype)) return (64 % (d->N * 2 / 16) == 0) ? (M + NK_BM - 1) / NK_BM : 0;
-    const TileCfg t = pick_tile(d, true, false);
-    const SplitK sk = plan_splitk(d, dtype, t);
-    if ((t.bm == 128 || t.bm == 256) && (t.bn == GP_BN || (t.bn == 64 && patch64()) || (t.bn == 32 && d->N == 32 && patch32())) &&
-        sk.ksplit <= 1 && use_patch() && use_dma() && d->zeros != nullptr && patch_geometry(d, t.bm, &pg))
-        return d->nphase * (M / t.bm);
-    return 0;
-}
-}  // namespace
-
-extern "C" int vg_gather_gemm_bnb_nparts(const vg_gg_desc* d, int dtype) {
-    int rc = validate(d, dtype);
-    if (rc) return rc;
-    return bnb_parts(d, dtype);
 }
 
 extern "C" int vg_gather_gemm_family(const vg_gg_desc* d, int dtype) {
@@ -903,11 +842,6 @@ extern "C" int vg_gather_gemm_family(const vg_gg_desc* d, int dtype) {
 extern "C" int vg_gather_gemm_tile_m(const vg_gg_desc* d, int dtype) {
     int rc = validate(d, dtype);
     if (rc) return rc;
-    PatchGeo pg;
-    StatPlan sp;
-    if (stationary_plan(d, dtype, &pg, &sp)) return sp.tiles_per_wg * GS_BM;          // rows behind one slab row
-    RegwPlan rp;
-    if (regw_plan(d, dtype, &pg, &rp)) return rp.tiles_per_wg * GR_BM;
     return pick_tile(d, dtype == VG_BF16, dtype == VG_FP8).bm;
 }
 
@@ -920,23 +854,7 @@ extern "C" int64_t vg_gather_gemm_ws_bytes(const vg_gg_desc* d, int dtype) {
 extern "C" int vg_gather_gemm(const vg_gg_desc* d, int dtype, void* stream) {
     int rc = validate(d, dtype);
     if (rc) return rc;
-    if (d->bnb_y != nullptr) {                                  // BatchNorm-backward sums in the epilogue: probe first
-        VG_CHECK_ARG(d->bnb_coeffs && d->bnb_partial && vg_aligned16(d->bnb_y) && d->mask_x == nullptr && d->stats == nullptr, VG_EINVAL);
-        const int np = bnb_parts(d, dtype);
-        if (np <= 0) return VG_ENOSUP;
-        VG_CHECK_ARG(d->bnb_capacity >= np, VG_EINVAL);
-    }
     PatchGeo pg;
-    StatPlan sp;
-    if (stationary_plan(d, dtype, &pg, &sp)) {                  // short-K transposed forms: weights resident in LDS
-        if (d->stats) VG_CHECK_ARG(d->stats_capacity >= d->nphase * sp.wgs_per_phase, VG_EINVAL);
-        return launch_stationary(d, pg, sp, vg_stream(stream));
-    }
-    RegwPlan rp;
-    if (regw_plan(d, dtype, &pg, &rp)) {                        // ... or in registers (two workgroups per CU)
-        if (d->stats) VG_CHECK_ARG(d->stats_capacity >= d->nphase * rp.wgs_per_phase, VG_EINVAL);
-        return launch_regw(d, pg, rp, vg_stream(stream));
-    }
     TileCfg t = pick_tile(d, dtype == VG_BF16, dtype == VG_FP8);
     const SplitK sk = plan_splitk(d, dtype, t);
     if (d->stats) {

@@ -21,10 +21,7 @@
 constexpr int NK_GP = VG_NK_GP;        // 16-pixel MFMA row groups per wave (4: 204 VGPRs at N=64, K=128 -> 2 waves per SIMD)
 constexpr int NK_BM = 64 * NK_GP;
 
-inline bool narrowk_enabled() {
-    const char* e = getenv("VG_EDGE");
-    return e ? atoi(e) != 0 : true;
-}
+inline bool narrowk_enabled() { return vg_sw().edge != 0; }      // VG_EDGE (common.hpp: switches are read once at load)
 
 // host: does the descriptor have the narrow-K form?
 inline bool narrowk_ok(const vg_gg_desc* d, int dtype) {
@@ -45,7 +42,7 @@ __device__ __forceinline__ int nk_fdiv(int a, int b, float inv) {      // a / b 
     return q;
 }
 
-template <int NT, int KC, bool BNB = false>     // N = 16 * NT output channels, Kp = 32 * KC; BNB: vg_gg_desc::bnb_* epilogue
+template <int NT, int KC>                       // N = 16 * NT output channels, Kp = 32 * KC
 __global__ __launch_bounds__(256) void ggn_kernel(const vg_gg_desc d) {
     // per-wave C staging [64 pixels][N] bf16 (+16 B pad per pixel row) | stats scratch [4 waves][N][2]
     constexpr int N = NT * 16, CP = N * 2 + 16;
@@ -60,23 +57,7 @@ __global__ __launch_bounds__(256) void ggn_kernel(const vg_gg_desc d) {
     const float inv_ghw = 1.0f / (float)GHW, inv_gw = 1.0f / (float)d.GW;
     const int tw_inv = (256 + d.TW - 1) / d.TW;               // exact for taps < 16, TW <= 4
 
-    // BatchNorm-backward sums of the layer below (BNB, see conv_patch.hpp): the raw outputs y of this wave's 64 pixels are
-    // requested first of all, so they arrive beside the A gather instead of adding a second HBM round trip to the epilogue
     constexpr int SEGS = NT * 16 * 2 / 16;                                    // 16-byte segments per pixel
-    constexpr bool BNB_OK = BNB && (64 % SEGS == 0);                          // a lane keeps segment lane % SEGS (N = 16 | 32 | 64)
-    constexpr int YIT = 16 * NK_GP * SEGS / 64;
-    u32x4 yq[BNB_OK ? YIT : 1];
-    if constexpr (BNB_OK) {
-#pragma unroll
-        for (int it = 0; it < YIT; ++it) {
-            const int u = lane + 64 * it;
-            const int m = m0 + u / SEGS;
-            yq[it] = u32x4{0u, 0u, 0u, 0u};
-            if (m < M)
-                yq[it] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(d.bnb_y) +
-                                                         (int64_t)m * (NT * 32) + (u % SEGS) * 16);
-        }
-    }
 
     // ---- weights: all of them, in registers ----
     bf16x8 bw[NT][KC];
@@ -180,18 +161,6 @@ __global__ __launch_bounds__(256) void ggn_kernel(const vg_gg_desc d) {
                     ElemT<VG_BF16>::from_f32(acc[g][nt][r]);
     __syncthreads();
     unsigned char* Yb = reinterpret_cast<unsigned char*>(d.Y);
-    const bool bnb = BNB_OK;
-    const int bc0 = (lane % SEGS) * 8;
-    float b_mu[8], b_is[8], b_sc[8], b_sh[8], b_s1[8], b_s2[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        b_mu[k] = bnb ? d.bnb_coeffs[bc0 + k] : 0.f;
-        b_is[k] = bnb ? d.bnb_coeffs[N + bc0 + k] : 0.f;
-        b_sc[k] = bnb ? d.bnb_coeffs[2 * N + bc0 + k] : 0.f;
-        b_sh[k] = bnb ? d.bnb_coeffs[3 * N + bc0 + k] : 0.f;
-        b_s1[k] = 0.f;
-        b_s2[k] = 0.f;
-    }
 #pragma unroll
     for (int it = 0; it < 16 * NK_GP * SEGS / 64; ++it) {
         const int u = lane + 64 * it;
@@ -200,39 +169,6 @@ __global__ __launch_bounds__(256) void ggn_kernel(const vg_gg_desc d) {
         if (m < M) {
             const u32x4 v = *reinterpret_cast<const u32x4*>(cw + row * CP + seg * 16);
             *reinterpret_cast<u32x4*>(Yb + (int64_t)m * (N * 2) + seg * 16) = v;
-            if constexpr (BNB_OK) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const uint32_t wy = yq[it][k >> 1], wg = v[k >> 1];
-                    const float yv = __uint_as_float((k & 1) ? (wy & 0xffff0000u) : (wy << 16));
-                    const float gr = __uint_as_float((k & 1) ? (wg & 0xffff0000u) : (wg << 16));
-                    const float dz = act_bwd(b_sc[k] * yv + b_sh[k], gr, d.bnb_act, d.bnb_slope);
-                    b_s1[k] += dz;
-                    b_s2[k] += dz * ((yv - b_mu[k]) * b_is[k]);
-                }
-            }
-        }
-    }
-    if (bnb) {
-        // lanes of one segment (lane % SEGS): butterfly over the other lane bits; then the 4 waves through LDS
-        __syncthreads();                                                       // every wave is done with its C staging
-        float* pr = reinterpret_cast<float*>(smem);                            // [wave][SEGS][16]
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-#pragma unroll
-            for (int o = SEGS; o < 64; o <<= 1) { b_s1[k] += __shfl_xor(b_s1[k], o); b_s2[k] += __shfl_xor(b_s2[k], o); }
-        }
-        if (lane < SEGS) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { pr[(wave * SEGS + lane) * 16 + k] = b_s1[k]; pr[(wave * SEGS + lane) * 16 + 8 + k] = b_s2[k]; }
-        }
-        __syncthreads();
-        if (tid < SEGS * 16) {
-            const int sg = tid >> 4, k = tid & 15;
-            float a = 0.f;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) a += pr[(w * SEGS + sg) * 16 + k];
-            d.bnb_partial[((int64_t)blockIdx.x * 2 + (k >> 3)) * N + sg * 8 + (k & 7)] = a;
         }
     }
 }
@@ -241,11 +177,7 @@ inline int launch_narrowk(const vg_gg_desc* d, hipStream_t s) {
     const int M = d->B * d->GH * d->GW;
     dim3 grid((M + NK_BM - 1) / NK_BM), block(256);
     const int NT = d->N / 16, KC = d->Kp / 32;
-#define NK_LAUNCH(A, B)                                                                         \
-    do {                                                                                        \
-        if (d->bnb_y != nullptr) vg_launch_timed(2, (ggn_kernel<A, B, true>), grid, block, 0, s, *d); \
-        else vg_launch_timed(2, (ggn_kernel<A, B>), grid, block, 0, s, *d);                     \
-    } while (0)
+#define NK_LAUNCH(A, B) vg_launch_timed(2, (ggn_kernel<A, B>), grid, block, 0, s, *d)
     if (NT == 1) { if (KC == 1) NK_LAUNCH(1, 1); else if (KC == 2) NK_LAUNCH(1, 2); else if (KC == 3) NK_LAUNCH(1, 3); else NK_LAUNCH(1, 4); }
     else if (NT == 2) { if (KC == 1) NK_LAUNCH(2, 1); else if (KC == 2) NK_LAUNCH(2, 2); else if (KC == 3) NK_LAUNCH(2, 3); else NK_LAUNCH(2, 4); }
     else if (NT == 3) { if (KC == 1) NK_LAUNCH(3, 1); else if (KC == 2) NK_LAUNCH(3, 2); else if (KC == 3) NK_LAUNCH(3, 3); else NK_LAUNCH(3, 4); }

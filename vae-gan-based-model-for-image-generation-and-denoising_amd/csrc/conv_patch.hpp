@@ -476,36 +476,8 @@ __global__ __launch_bounds__(128 * WM, gp_min_waves(WM, BN, NR_)) void ggp_kerne
                 *dst = E::from_f32(acc[i][j][r]);
 #endif
             }
-    // BatchNorm-backward sums of the layer below (vg_gg_desc::bnb_*): this thread's segment is the same 8 channels in
-    // every iteration (NT % SEGS == 0), so their coefficients and the 16 running sums live in registers.  The raw
-    // outputs y it needs (one 16-byte segment per iteration) and the coefficients are requested HERE, before the barrier:
-    // the accumulators are dead, and the loads fly under the barrier and the C-tile reads instead of adding a dependent
-    // HBM round trip per iteration to the store loop.
     constexpr int YIT = (BM * SEGS) / NT;
-    static_assert(NT % SEGS == 0 && (BM * SEGS) % NT == 0, "a thread keeps one channel segment");
-    const bool bnb = d.bnb_y != nullptr;
-    const int bseg = tid % SEGS, bc0 = n0 + bseg * 8;
-    float b_mu[8], b_is[8], b_sc[8], b_sh[8], b_s1[8], b_s2[8];
-    u32x4 yq[YIT];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const bool okc = bnb && bc0 + k < d.N;
-        b_mu[k] = okc ? d.bnb_coeffs[bc0 + k] : 0.f;
-        b_is[k] = okc ? d.bnb_coeffs[d.N + bc0 + k] : 0.f;
-        b_sc[k] = okc ? d.bnb_coeffs[2 * d.N + bc0 + k] : 0.f;
-        b_sh[k] = okc ? d.bnb_coeffs[3 * d.N + bc0 + k] : 0.f;
-        b_s1[k] = 0.f;
-        b_s2[k] = 0.f;
-    }
-#pragma unroll
-    for (int it = 0; it < YIT; ++it) {
-        const int row = (tid + it * NT) / SEGS;
-        const int op = opix_tab[row];
-        const int cb = n0 * ESZ + bseg * 16;
-        yq[it] = u32x4{0u, 0u, 0u, 0u};
-        if (bnb && op >= 0 && cb < oc_bytes)
-            yq[it] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(d.bnb_y) + (int64_t)op * oc_bytes + cb);
-    }
+    static_assert((BM * SEGS) % NT == 0, "whole store iterations");
     GP_SYNC();
 #pragma unroll
     for (int it = 0; it < YIT; ++it) {
@@ -523,43 +495,13 @@ __global__ __launch_bounds__(128 * WM, gp_min_waves(WM, BN, NR_)) void ggp_kerne
 #else
             *reinterpret_cast<u32x4*>(Yb + (int64_t)op * oc_bytes + cb) = v;
 #endif
-            if (bnb) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const uint32_t wy = yq[it][k >> 1], wg = v[k >> 1];
-                    const float yv = __uint_as_float((k & 1) ? (wy & 0xffff0000u) : (wy << 16));
-                    const float gr = __uint_as_float((k & 1) ? (wg & 0xffff0000u) : (wg << 16));
-                    const float dz = act_bwd(b_sc[k] * yv + b_sh[k], gr, d.bnb_act, d.bnb_slope);
-                    b_s1[k] += dz;
-                    b_s2[k] += dz * ((yv - b_mu[k]) * b_is[k]);
-                }
-            }
-        }
-    }
-    if (bnb) {
-        // workgroup sums: [NT][16] floats through LDS (the C tile has been read), then one thread per (segment, sum)
-        GP_SYNC();
-        float* pr = reinterpret_cast<float*>(smem);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { pr[tid * 16 + k] = b_s1[k]; pr[tid * 16 + 8 + k] = b_s2[k]; }
-        GP_SYNC();
-        if (tid < SEGS * 16) {
-            const int sg = tid >> 4, k = tid & 15;
-            float a = 0.f;
-            for (int j = 0; j < NT / SEGS; ++j) a += pr[(sg + SEGS * j) * 16 + k];
-            const int c = n0 + sg * 8 + (k & 7);
-            const int64_t part = (int64_t)phase * m_tiles_ + bx;
-            if (c < d.N) d.bnb_partial[(part * 2 + (k >> 3)) * d.N + c] = a;
         }
     }
 }
 
 #undef GP_SYNC
 
-inline bool use_patch() {                   // read per call: tests flip it inside one process
-    const char* e = getenv("VG_GG_PATCH");
-    return e ? atoi(e) != 0 : true;
-}
+inline bool use_patch() { return vg_sw().gg_patch != 0; }      // VG_GG_PATCH (common.hpp: switches are read once at load)
 
 // Does the descriptor have one of the two patch forms, and does a bm-row tiling (128 or 256) line up?
 inline bool patch_geometry(const vg_gg_desc* d, int bm, PatchGeo* g) {

@@ -77,28 +77,6 @@ __global__ __launch_bounds__(256) void tnconv_kernel(const vg_tn_desc d, const i
                 if (g < ngroups) v = *reinterpret_cast<const u32x4*>(Xb + (int64_t)(g * 16 + fr) * (KC * 64) + kc * 64 + fg * 16);
                 a[u][kc] = v;
             }
-        if (d.in_scale != nullptr) {
-            // X is the raw output of the layer below: its BatchNorm + activation applied here, on the 8 channels
-            // (kc*32 + fg*8 ...) this lane holds of every pixel -- the bf16 value vg_bn_act_forward would have stored
-#pragma unroll
-            for (int kc = 0; kc < KC; ++kc) {
-                float sc[8], sh[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { sc[e] = d.in_scale[kc * 32 + fg * 8 + e]; sh[e] = d.in_shift[kc * 32 + fg * 8 + e]; }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    if (wave * U + u < ngroups) {
-#pragma unroll
-                        for (int k2 = 0; k2 < 4; ++k2) {
-                            const uint32_t w = a[u][kc][k2];
-                            const float lo = act_fwd(sc[2 * k2] * __uint_as_float(w << 16) + sh[2 * k2], d.in_act, d.in_slope);
-                            const float hi = act_fwd(sc[2 * k2 + 1] * __uint_as_float(w & 0xffff0000u) + sh[2 * k2 + 1], d.in_act, d.in_slope);
-                            a[u][kc][k2] = (uint32_t)ElemT<VG_BF16>::from_f32(lo) | ((uint32_t)ElemT<VG_BF16>::from_f32(hi) << 16);
-                        }
-                    }
-                }
-            }
-        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int g = wave * U + u;
@@ -181,8 +159,6 @@ inline int tn_plan(const vg_tn_desc* d, TnPlan* p) {
     VG_CHECK_ARG(d->OH == (d->IH - 1) * d->S - 2 * d->P + d->K && d->OW == (d->IW - 1) * d->S - 2 * d->P + d->K, VG_EINVAL);
     VG_CHECK_ARG(vg_aligned16(d->X) && vg_aligned16(d->Wp) && vg_aligned16(d->Y), VG_EALIGN);
     VG_CHECK_ARG(d->act == VG_ACT_NONE || d->act == VG_ACT_TANH, VG_EINVAL);
-    VG_CHECK_ARG((d->in_scale == nullptr) == (d->in_shift == nullptr), VG_EINVAL);
-    VG_CHECK_ARG(d->in_scale == nullptr || d->in_act == VG_ACT_NONE || d->in_act == VG_ACT_RELU || d->in_act == VG_ACT_LRELU, VG_EINVAL);
     VG_CHECK_ARG(d->draw >= 0 && d->draw < 256, VG_EINVAL);
     const int NJ = d->K * d->K * d->N;
     VG_CHECK_ARG(NJ <= 64, VG_ENOSUP);
@@ -260,13 +236,8 @@ __global__ __launch_bounds__(256) void edge_wgrad_kernel(const vg_ew_desc d, con
     const int tapoff = tap_ok ? (kh * PW + kw) * 16 : 0;
 
     f32x4 acc[CT];
-    float in_sc[CT], in_sh[CT];                                   // prologue coefficients of this lane's channel per tile
 #pragma unroll
-    for (int c = 0; c < CT; ++c) {
-        acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-        in_sc[c] = d.in_scale != nullptr ? d.in_scale[c * 16 + (lane & 15)] : 1.f;
-        in_sh[c] = d.in_scale != nullptr ? d.in_shift[c * 16 + (lane & 15)] : 0.f;
-    }
+    for (int c = 0; c < CT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const unsigned char* Wb = reinterpret_cast<const unsigned char*>(d.Wd);
     const unsigned char* Nb = reinterpret_cast<const unsigned char*>(d.Nr);
@@ -330,19 +301,7 @@ __global__ __launch_bounds__(256) void edge_wgrad_kernel(const vg_ew_desc d, con
                     const unsigned char* b1 = wide + r1 * RB + ((c ^ f1) << 5) + 8 * p;
                     const ew_bf16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) ew_bf16x4*)b0);
                     const ew_bf16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) ew_bf16x4*)b1);
-                    bf16x8 bf = __builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7);
-                    if (d.in_scale != nullptr) {
-                        // 8 pixels of ONE channel (16 c + lane & 15): BatchNorm + activation of the layer that produced
-                        // the wide operand (rows past the tile are multiplied by the zero pixel of the narrow side)
-                        u32x4 w = __builtin_bit_cast(u32x4, bf);
-#pragma unroll
-                        for (int k2 = 0; k2 < 4; ++k2) {
-                            const float lo = act_fwd(in_sc[c] * __uint_as_float(w[k2] << 16) + in_sh[c], d.in_act, d.in_slope);
-                            const float hi = act_fwd(in_sc[c] * __uint_as_float(w[k2] & 0xffff0000u) + in_sh[c], d.in_act, d.in_slope);
-                            w[k2] = (uint32_t)ElemT<VG_BF16>::from_f32(lo) | ((uint32_t)ElemT<VG_BF16>::from_f32(hi) << 16);
-                        }
-                        bf = __builtin_bit_cast(bf16x8, w);
-                    }
+                    const bf16x8 bf = __builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7);
                     acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, acc[c], 0, 0, 0);
                 }
             }

@@ -806,6 +806,41 @@ extern "C" int vg_axpy(const float* a, const float* b, float alpha, float* out, 
     return VG_LAUNCH_RC();
 }
 
+// ---- runtime switches (common.hpp): read once at load, re-read by vg_reload_switches() ----
+#include <cstdlib>
+namespace {
+VgSwitches g_sw;
+int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+void read_switches() {
+    g_sw.gg_dma = env_int("VG_GG_DMA", 1);
+    g_sw.tile_min_wgs = env_int("VG_TILE_MIN_WGS", 512);
+    g_sw.gg_patch = env_int("VG_GG_PATCH", 1);
+    g_sw.gg_patch64 = env_int("VG_GG_PATCH64", 1);
+    g_sw.gg_patch32 = env_int("VG_GG_PATCH32", 1);
+    g_sw.gg_patch_nr3 = env_int("VG_GG_PATCH_NR3", 1);
+    g_sw.patch256_min = env_int("VG_PATCH256_MIN", 256);
+    g_sw.patch256x64_min = env_int("VG_PATCH256X64_MIN", 512);
+    g_sw.splitk_max_tiles = env_int("VG_SPLITK_MAX_TILES", 32);
+    g_sw.gg_nmajor = env_int("VG_GG_NMAJOR", 1);
+    g_sw.edge = env_int("VG_EDGE", 1);
+    g_sw.wg_reduce_t = env_int("VG_WG_REDUCE_T", 1);
+    g_sw.wg_target = env_int("VG_WG_TARGET", 512);
+    g_sw.wg_spec = env_int("VG_WG_SPEC", 3);
+    g_sw.wg_dma = env_int("VG_WG_DMA", 1);
+    g_sw.wg_xcd = env_int("VG_WG_XCD", 1);
+    g_sw.bn_fused_fwd = env_int("VG_BN_FUSED_FWD", 1);
+}
+struct SwitchInit { SwitchInit() { read_switches(); } } g_switch_init;
+}  // namespace
+const VgSwitches& vg_sw() { return g_sw; }
+extern "C" int vg_reload_switches(void) {
+    read_switches();
+    return 0;
+}
+
 VgTiming& vg_timing() {
     static VgTiming t;
     return t;

@@ -824,8 +824,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_t_kernel(const vg_wg_desc d,
 // the streaming reduce takes: <= 16 taps, contiguous taps, channel stride == tap count, whole 64-channel tiles,
 // 16-byte aligned runs
 inline bool Ttaps_ok(const vg_wg_desc* d) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("VG_WG_REDUCE_T"); on = e ? atoi(e) : 1; }
+    const int on = vg_sw().wg_reduce_t;
     const int T = d->TH * d->TW;
     return on && T <= 16 && d->s_t == 1 && d->s_cq == T && d->QC % 64 == 0 && d->NQ == d->QC && (d->s_np % 4) == 0 &&
            ((64 * T) % 4) == 0 && vg_aligned16(d->dW);
@@ -833,30 +832,15 @@ inline bool Ttaps_ok(const vg_wg_desc* d) {
 
 struct Plan { int tiles_kq, tiles_np, nsplit, rows_per_split, KQ, NPpad, tile; int64_t ws_bytes; };
 
-inline int wg_target() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("VG_WG_TARGET");
-        v = e ? atoi(e) : 512;
-    }
-    return v;
-}
+inline int wg_target() { return vg_sw().wg_target; }
 
 // 0: one role per wave (wgrad_bf16_dma_kernel); 1: 128 x 128 tile, 4 consumer + 8 producer waves; 2: 128 x 256 tile,
-// 8 consumers + 4 producers; 3 (default): 128 x 256 tile, 8 consumers + 8 producers.  Read per call (tests, A/B scripts).
-inline int wg_spec() {
-    const char* e = getenv("VG_WG_SPEC");
-    return e ? atoi(e) : 3;
-}
+// 8 consumers + 4 producers; 3 (default): 128 x 256 tile, 8 consumers + 8 producers.
+inline int wg_spec() { return vg_sw().wg_spec; }
 
 inline bool wg_use_dma(const vg_wg_desc* d) {
-    static int v = -1;
-    if (v < 0) {
-        // default on with 64-row stages (+5..10 % on the generator layers); VG_WG_DMA=0 -> register-staged kernel
-        const char* e = getenv("VG_WG_DMA");
-        v = e ? atoi(e) : 1;
-    }
-    return v != 0 && d->zeros != nullptr;
+    // default on with 64-row stages (+5..10 % on the generator layers); VG_WG_DMA=0 -> register-staged kernel
+    return vg_sw().wg_dma != 0 && d->zeros != nullptr;
 }
 
 inline int make_plan(const vg_wg_desc* d, int dtype, Plan* p) {
@@ -911,7 +895,7 @@ extern "C" int vg_wgrad(const vg_wg_desc* d, int dtype, void* stream) {
     dim3 grid(p.tiles_kq, p.tiles_np, p.nsplit);
     // XCD-aware order (wg_tile) where it pays: few tiles per split, many splits, long operands (measured S=64 B=128:
     // G4 81 -> 55 us, D1 2B 44 -> 31, D1 26 -> 21, G3 55 -> 54; layers with >= 128 tiles per split lose 2-3 us)
-    const int xcd_env = [] { const char* e = getenv("VG_WG_XCD"); return e ? atoi(e) : 1; }();      // per call: tests flip it
+    const int xcd_env = vg_sw().wg_xcd;
     const int64_t Mrows = (int64_t)d->B * d->GH * d->GW;
     const int xcd_order = xcd_env == 2 || (xcd_env == 1 && p.tiles_kq * p.tiles_np <= 32 && p.nsplit >= 16 && Mrows >= 32768);
     if (dtype == VG_F32)

@@ -24,9 +24,10 @@ from . import ops
 from ._lib import VG_ACT_LRELU, VG_ACT_NONE, VG_ACT_RELU, VG_ACT_TANH, VG_FP8_WSHIFT
 
 BN_MOMENTUM, BN_EPS = 0.1, 1e-5       # nn.BatchNorm2d defaults (main_vae.py:24, gan_code.py:22)
-
-_SIDE = {}
-
+# VG_EDGE=0 / VG_EDGE_WGRAD=0 (read once, at import): the 3-channel image layers on the generic gather-GEMM / wgrad kernels
+# instead of the edge-layer kernels (csrc/edge_conv.hip, conv_narrowk.hpp) -- A/B and test switch
+_EDGE = os.environ.get("VG_EDGE", "1") != "0"
+_EDGE_WGRAD = os.environ.get("VG_EDGE_WGRAD", "1") != "0"
 
 class no_gc_while_capturing:
     """Context for a hipGraph capture: collect garbage first and keep Python's cyclic collector off until the capture has
@@ -47,14 +48,6 @@ class no_gc_while_capturing:
         if self._was:
             gc.enable()
         return False
-
-
-def side_stream(device) -> "torch.cuda.Stream":
-    """One low-priority stream per device for work that is off the critical path of a backward pass."""
-    key = str(device)
-    if key not in _SIDE:
-        _SIDE[key] = torch.cuda.Stream(device=device, priority=0)
-    return _SIDE[key]
 
 
 def fused_pair(a: torch.Tensor, b: torch.Tensor):
@@ -168,21 +161,6 @@ class StackEngine:
         self._pack_ptrs = None
         self.pending_bn_ticks = 0           # num_batches_tracked increments not yet applied (flushed lazily)
         self.bn_sync = None                 # ddp.GradReducer -> BatchNorm statistics over all ranks (SyncBN mode)
-        # Weight/bias gradients of a stage feed nothing downstream in the backward pass: launched on a side stream
-        # they could overlap the latency-bound BatchNorm-backward chain (reduce -> finalize -> apply, ~25 us of
-        # 5-10 us kernels) of the next stage.  MEASURED SLOWER on MI355X (S=64, B=128: 34.0k vs 35.9k img/s; with
-        # a high-priority main stream 17.5k): the concurrent wgrad and dgrad grids evict each other's L2/LDS
-        # residency and the small kernels queue behind full CUs.  Kept as an opt-in experiment (VG_SIDE_WGRAD=1).
-        self.side_wgrad = os.environ.get("VG_SIDE_WGRAD", "0") == "1"
-        # VG_SIDE_WGRAD=2: the same idea with a join per stage -- stage i's weight gradient is forked AFTER its data
-        # gradient and joined before the NEXT data gradient, so it runs beside the BatchNorm-backward chain of stage
-        # i-1 only and two GEMM-class grids never share the chip.
-        self.wgrad_under_bn = os.environ.get("VG_SIDE_WGRAD", "0") == "2"
-        # VG_BNB=1: BatchNorm-backward sums of stage i-1 in the epilogue of stage i's data-gradient GEMM (no reduce pass:
-        # 7 launches fewer per iteration).  MEASURED NEUTRAL (2.816 / 2.820 vs 2.821 / 2.810 ms, tools/ab_bnb.sh): the
-        # reduce passes go (-67 us) but the GEMM epilogues that now read the raw output grow by as much (+62 us,
-        # tools/ab_bnb_trace.sh) -- the bytes are the same HBM bytes either way.  Opt-in.
-        self.bnb_epilogue = os.environ.get("VG_BNB", "0") == "1"
 
     # ---- geometry (cached per batch size) -----------------------------------------------------
     def spec(self, i: int, B: int, what: str):
@@ -221,7 +199,7 @@ class StackEngine:
         key = (i, B, "edge_wg")
         if key not in self._specs:
             st, sp = self.stages[i], None
-            if os.environ.get("VG_EDGE", "1") != "0" and os.environ.get("VG_EDGE_WGRAD", "1") != "0":
+            if _EDGE and _EDGE_WGRAD:
                 a = (B, st.hin, st.hin, st.cin, st.cout, st.k, st.s, st.p, self.dtype)
                 if st.kind == "conv" and st.cin <= 3 and G.padc(st.cin, self.dtype) == 8:
                     sp = G.conv_wgrad_edge(*a)
@@ -236,28 +214,13 @@ class StackEngine:
         key = (i, B, "tn_" + what)
         if key not in self._specs:
             st, sp = self.stages[i], None
-            if os.environ.get("VG_EDGE", "1") != "0" and st.bn is None and not st.has_bias:
+            if _EDGE and st.bn is None and not st.has_bias:
                 a = (B, st.hin, st.hin, st.cin, st.cout, st.k, st.s, st.p, self.dtype)
                 if st.kind == "convT" and what == "fprop" and st.act == VG_ACT_NONE:
                     sp = G.convT_fprop_tn(*a)
                 elif st.kind == "conv" and what == "dgrad":
                     sp = G.conv_dgrad_tn(*a)
             self._specs[key] = sp
-        return self._specs[key]
-
-    def edge_prologue(self, i: int, B: int, groups: int = 1) -> bool:
-        """Stage i's BatchNorm + activation can ride in stage i+1's kernels (no vg_bn_act_forward pass, no activated
-        copy: 67 MB less activation memory at S=64 B=128): stage i+1 is an edge layer whose forward runs on vg_tnconv and
-        whose weight gradient on vg_edge_wgrad, both of which take an input prologue.  OPT-IN (VG_EDGE_PROLOGUE=1):
-        bit-exact, but measured slower on MI355X (tools/prologue_bench.py, the Generator's last layer: the 29.5 us pass
-        it removes against +15.8 us in vg_tnconv and +46.5 us in vg_edge_wgrad, whose three tap-tile waves each convert
-        every wide fragment: step 2.766 vs 2.742 ms)."""
-        key = (i, B, groups, "edge_prologue")
-        if key not in self._specs:
-            ok = (os.environ.get("VG_EDGE_PROLOGUE", "0") == "1" and groups == 1 and self.dtype == G.BF16 and
-                  i + 1 < len(self.stages) and self.stages[i].bn is not None and self.stages[i + 1].kind == "convT" and
-                  self.tn(i + 1, B, "fprop") is not None and self.edge_wg(i + 1, B) is not None)
-            self._specs[key] = ok
         return self._specs[key]
 
     # ---- parameter handling ---------------------------------------------------------------------
@@ -378,7 +341,6 @@ class StackEngine:
         ctx = []
         a = x
         a8 = None                             # e4m3 twin of `a` when the producing pass already made one (fp8 engines)
-        a_pre = None                          # (scale, shift, act, slope): `a` is RAW, the consumer applies this BatchNorm + act
         Bg, B = B, B * groups
         for i, st in enumerate(self.stages):
             if st.kind == "head":
@@ -395,19 +357,16 @@ class StackEngine:
                 if tail is not None and i == len(self.stages) - 1:
                     Yn, img = ops.tnconv(tnsp, a, packs[i]["tn_fprop"], want_nhwc=tail.get("out_noisy") is not None,
                                          want_nchw=True, act=VG_ACT_TANH, noise=tail.get("noise"),
-                                         sigma=tail.get("sigma", 0.0), out_nhwc=tail.get("out_noisy"), alg=st.alg(B, dt),
-                                         pre=a_pre)
+                                         sigma=tail.get("sigma", 0.0), out_nhwc=tail.get("out_noisy"), alg=st.alg(B, dt))
                     out = img
                     Yshape = (B, st.hout, st.hout, OC)
                 else:
-                    out, _ = ops.tnconv(tnsp, a, packs[i]["tn_fprop"], alg=st.alg(B, dt), pre=a_pre)
+                    out, _ = ops.tnconv(tnsp, a, packs[i]["tn_fprop"], alg=st.alg(B, dt))
                     Yshape = tuple(out.shape)
                 if keep:
-                    # "x" is the RAW output of the stage below when x_pre is set (its BatchNorm + activation ride in this
-                    # stage's kernels: forward above, weight gradient in _param_grads)
-                    ctx.append({"x": a, "x_pre": a_pre, "Y": None, "Yshape": Yshape, "coeffs": None,
+                    ctx.append({"x": a, "Y": None, "Yshape": Yshape, "coeffs": None,
                                 "rows": B * st.hout * st.hout, "OC": OC})
-                a, a8, a_pre = out, None, None
+                a, a8 = out, None
                 continue
             gg, pk = self.spec(i, B, "fprop")
             want_stats = st.bn is not None and train
@@ -433,13 +392,11 @@ class StackEngine:
             if want_stats and not epilogue_stats:
                 stats, nparts = ops.channel_stats(Y, rows, OC, dt)
             coeffs = None
-            nxt_pre = None
             if st.bn is not None:
                 bn = st.bn
                 nxt8 = i + 1 < len(self.stages) and self.stages[i + 1].kind != "head" and self.fp8_ok(i + 1)
-                lazy = self.edge_prologue(i, B, groups) and not nxt8 and st.cout == OC
                 fused = None
-                if train and self.bn_sync is None and not nxt8 and st.cout == OC and not lazy:
+                if train and self.bn_sync is None and not nxt8 and st.cout == OC:
                     # small statistics slab: finalize + normalise + activation in one launch
                     fused = ops.bn_finalize_act_forward(Y, stats, nparts, OC, rows, bn.weight.detach(), bn.bias.detach(),
                                                         bn.running_mean, bn.running_var, BN_MOMENTUM, BN_EPS, st.act,
@@ -453,10 +410,7 @@ class StackEngine:
                 else:
                     coeffs = ops.bn_eval_coeffs(bn.weight.detach(), bn.bias.detach(), bn.running_mean,
                                                 bn.running_var, BN_EPS)
-                if lazy:
-                    # the next stage's edge kernels apply this BatchNorm + activation on their operand loads
-                    out, out8, nxt_pre = Y, None, (coeffs[0, 2], coeffs[0, 3], st.act, st.slope)
-                elif fused is not None:
+                if fused is not None:
                     out, out8 = fused[1], None
                 elif nxt8:                                  # the next layer's fp8 operand comes out of this same pass
                     out, out8 = ops.bn_act_forward(Y, coeffs, rows, OC, st.act, st.slope, dt, want_fp8=True)
@@ -466,7 +420,7 @@ class StackEngine:
                 out, out8 = Y, None                         # activation (if any) already applied by the epilogue
             if keep:
                 ctx.append({"x": a, "Y": Y, "coeffs": coeffs, "rows": rows, "OC": OC})
-            a, a8, a_pre = out, out8, nxt_pre
+            a, a8 = out, out8
         if train and any(st.bn is not None for st in self.stages):
             self.pending_bn_ticks += groups
         return a, (ctx, B, train)
@@ -482,60 +436,22 @@ class StackEngine:
                         out[id(p)] = i
         return out
 
-    @staticmethod
-    def run_deferred(deferred, device) -> None:
-        """Launch weight-gradient work collected by backward(defer=...) on the side stream, forked from the current
-        stream.  The caller joins with join_deferred() before anything reads the gradients."""
-        if not deferred:
-            return
-        side = side_stream(device)
-        side.wait_stream(torch.cuda.current_stream())
-        ops.set_ws_suffix(".side")
-        try:
-            with torch.cuda.stream(side):
-                for fn in deferred:
-                    fn()
-        finally:
-            ops.set_ws_suffix(None)
-
-    @staticmethod
-    def join_deferred(deferred, device) -> None:
-        if deferred:
-            torch.cuda.current_stream().wait_stream(side_stream(device))
-            deferred.clear()                  # the closures kept the operands alive until here
-
     def backward(self, ctxpack, dout: torch.Tensor, need_dx: bool, sink: GradSink, param_grads: bool = True,
-                 on_grads=None, defer=None):
+                 on_grads=None):
         """dout: gradient w.r.t. forward()'s output.  Returns the gradient w.r.t. the NHWC input (or None).
         param_grads=False skips every weight/bias/BN-parameter gradient (legal when the caller discards
         them, e.g. the generator-loss pass through the discriminator).
         on_grads(i): called right after every parameter gradient of stage i has been enqueued (stages run
         last-to-first) -- the data-parallel trainer launches a gradient bucket's all-reduce from it.
-        defer: a list -> the conv weight / bias gradient launches are NOT issued but appended to it as closures (the
-        data-gradient chain, which is the critical path, runs alone); the caller launches them with run_deferred()
-        beside later work and joins before the optimizer step."""
+        Everything runs on the current stream: forking weight gradients onto a second stream (three schedules, rounds 1
+        and 2) measured slower every time and is gone ("Concurrency does not pay")."""
         ctx, B, train = ctxpack
         if not train:
             raise RuntimeError("backward through an eval-mode network is not supported (the reference never does it)")
         packs = self._ensure_packed()
         dt = self.dtype
         dA = dout
-        side = side_stream(dout.device) if (self.side_wgrad and param_grads) else None
-        fj = side_stream(dout.device) if (self.wgrad_under_bn and param_grads and defer is None) else None
-        forked = None                       # stage whose parameter gradients are in flight on the fork/join stream
-        held = []                           # tensors the side stream reads: kept alive until the join
         masked = False                      # dA already carries the activation backward of the stage it belongs to
-        bn_partial = None                   # (slabs, n): BatchNorm-backward sums of stage i, emitted by stage i+1's dgrad
-
-        def join_forked():
-            nonlocal forked
-            if forked is not None:
-                torch.cuda.current_stream().wait_stream(fj)
-                held.clear()
-                if on_grads is not None:
-                    on_grads(forked)
-                forked = None
-
         for i in range(len(self.stages) - 1, -1, -1):
             st, c = self.stages[i], ctx[i]
             want_dx = need_dx or i > 0
@@ -560,29 +476,15 @@ class StackEngine:
                 else:
                     gg_, gb_, acc_g = None, None, False
                 dY = ops.bn_act_backward(Y, dA, c["coeffs"], rows, OC, rows, st.bn.weight.detach(), st.act, st.slope,
-                                         gg_, gb_, acc_g, dt, sync=self.bn_sync, partial=bn_partial)
-                bn_partial = None
+                                         gg_, gb_, acc_g, dt, sync=self.bn_sync)
             elif st.act != VG_ACT_NONE and not masked:
                 dY = ops.act_backward(Y, dA, st.act, st.slope, dt)
             else:
                 dY = dA                                     # no activation, or its backward was fused into the dgrad above
             masked = False
-            fork_here = fj is not None and want_dx and i > 0
-            if fj is not None:
-                join_forked()               # stage i+1's parameter gradients ran beside this stage's BatchNorm backward
-            if param_grads and defer is not None:
-                defer.append(lambda i=i, st=st, c=c, dY=dY, rows=rows, OC=OC: self._param_grads(i, st, c, dY, B, rows, OC, sink))
-            elif param_grads and fork_here:
-                pass                        # launched below, after this stage's data gradient
-            elif param_grads:
-                if side is None:
-                    self._param_grads(i, st, c, dY, B, rows, OC, sink)
-                else:
-                    side.wait_stream(torch.cuda.current_stream())
-                    with torch.cuda.stream(side):
-                        self._param_grads(i, st, c, dY, B, rows, OC, sink)
-                    held.append(dY)
-                if on_grads is not None and side is None:
+            if param_grads:
+                self._param_grads(i, st, c, dY, B, rows, OC, sink)
+                if on_grads is not None:
                     on_grads(i)
             if want_dx and self.tn(i, B, "dgrad") is not None:
                 tnsp, _ = self.tn(i, B, "dgrad")            # image gradient below a narrow first Conv2d (edge layer)
@@ -598,32 +500,10 @@ class StackEngine:
                             ggd.OC == pc["OC"]:
                         mask = (pc["Y"], pst.act, pst.slope)
                         masked = True
-                bnb = None
-                if i > 0 and self.bnb_epilogue and self.bn_sync is None:
-                    pst, pc = self.stages[i - 1], ctx[i - 1]
-                    # the stage below has BatchNorm: this launch's epilogue also sums dz and dz*xhat over its tile, which
-                    # is the whole reduce pass of that BatchNorm's backward (ops.gather_gemm bnb=)
-                    if pst.bn is not None and pc.get("Y") is not None and pc["coeffs"].shape[0] == 1 and \
-                            ggd.N == pc["OC"] and pc["coeffs"].shape[-1] == ggd.N and \
-                            ops.gather_gemm_bnb_parts(ggd, dY, packs[i]["dgrad"], dt) > 0:
-                        bnb = (pc["Y"], pc["coeffs"][0], pst.act, pst.slope)
-                dX, slab, nslab = ops.gather_gemm(ggd, dY, packs[i]["dgrad"], dt, alg=st.alg(B, dt), mask=mask, bnb=bnb)
-                if bnb is not None:
-                    bn_partial = (slab, nslab)
+                dX, _, _ = ops.gather_gemm(ggd, dY, packs[i]["dgrad"], dt, alg=st.alg(B, dt), mask=mask)
                 dA = dX.view(c["x"].shape)
             else:
                 dA = None
-            if param_grads and defer is None and fork_here:
-                fj.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(fj):
-                    self._param_grads(i, st, c, dY, B, rows, OC, sink)
-                held.append(dY)
-                forked = i
-        if fj is not None:
-            join_forked()
-        if side is not None:
-            torch.cuda.current_stream().wait_stream(side)
-            held.clear()
         return dA
 
     def _param_grads(self, i, st, c, dY, B, rows, OC, sink):
@@ -654,16 +534,11 @@ class StackEngine:
         if ew is not None and gw.is_contiguous():
             # wide operand = the many-channel side, narrow = the 3-channel side (conv: dY / input image; convT: input / dY)
             wide, narrow = (dY, c["x"]) if st.kind == "conv" else (c["x"], dY)
-            ops.edge_wgrad(ew, wide, narrow, gw, acc, alg=st.alg(B, dt), pre=c.get("x_pre") if st.kind == "convT" else None)
+            ops.edge_wgrad(ew, wide, narrow, gw, acc, alg=st.alg(B, dt))
         elif st.kind == "conv":
             ops.wgrad(wg, dY, c["x"], gw, acc, dt, alg=st.alg(B, dt))
         else:
-            xin = c["x"]
-            if c.get("x_pre") is not None:      # raw input kept for the edge kernel, which was not taken: activate it now
-                sc, sh, act_, slope_ = c["x_pre"]
-                co = torch.stack([torch.zeros_like(sc), torch.zeros_like(sc), sc, sh]).unsqueeze(0).contiguous()
-                xin = ops.bn_act_forward(xin, co, xin.numel() // xin.shape[-1], xin.shape[-1], act_, slope_, dt)
-            ops.wgrad(wg, xin, dY, gw, acc, dt, alg=st.alg(B, dt))
+            ops.wgrad(wg, c["x"], dY, gw, acc, dt, alg=st.alg(B, dt))
         if st.has_bias:
             gb, accb = sink.get(st.conv.bias)
             ops.bias_grad(dY, rows, OC, st.cout, gb, accb, dt)

@@ -48,12 +48,12 @@ class _Workspace:
 
 
 WS = _Workspace()
-_WS_SUFFIX = None          # set by engine.run_deferred while launching on the side stream
 
 
-def set_ws_suffix(sfx) -> None:
-    global _WS_SUFFIX
-    _WS_SUFFIX = sfx
+def reload_switches() -> None:
+    """Re-read the library's optional VG_* kernel-selection switches from the environment (they are read once, when the
+    library is loaded: include/vaegan_hip.h vg_reload_switches).  For tests / A-B scripts that flip one in-process."""
+    L.check(L.load().vg_reload_switches(), "vg_reload_switches")
 
 
 class KernelTimer:
@@ -282,25 +282,9 @@ def _gg_desc(g: GGSpec, X, Wp, Y, bias, stats, cap) -> L.GGDesc:
                     OSY=g.OSY, OSX=g.OSX, ooy=L.i4(g.ooy), oox=L.i4(g.oox), nphase=g.nphase, stats_capacity=cap)
 
 
-def gather_gemm_bnb_parts(g: GGSpec, X: torch.Tensor, Wp: torch.Tensor, dtype: int) -> int:
-    """> 0 (the number of partial rows) when the launch of this descriptor can emit the BatchNorm-backward sums of the layer
-    below in its epilogue (gather_gemm(..., bnb=...)), else 0."""
-    if dtype != BF16:
-        return 0
-    probe = _gg_desc(g, X, Wp, X, None, None, 0)
-    r = L.load().vg_gather_gemm_bnb_nparts(byref(probe), dtype)
-    if r < 0:
-        L.check(r, "vg_gather_gemm_bnb_nparts")
-    return r
-
-
 def gather_gemm(g: GGSpec, X: torch.Tensor, Wp: torch.Tensor, dtype: int, bias: torch.Tensor = None,
-                want_stats: bool = False, out: torch.Tensor = None, alg=None, act=None, mask=None, bnb=None):
-    """Returns (Y [B,OH,OW,OC], stats slabs or None, nparts).  alg = (flops, bytes) of the layer for the timer.
-    bnb = (y, coeffs [4][N] f32, act, slope) on a data-gradient launch whose output is the gradient w.r.t. the activated
-    output of a BatchNorm layer (y: that layer's raw conv output, Y-shaped): the epilogue also emits the backward partial
-    sums (sum dz | sum dz*xhat) -- returned in place of the stats slabs, with their row count -- so that
-    bn_act_backward(partial=...) needs no reduce pass.  Only where gather_gemm_bnb_parts() > 0."""
+                want_stats: bool = False, out: torch.Tensor = None, alg=None, act=None, mask=None):
+    """Returns (Y [B,OH,OW,OC], stats slabs or None, nparts).  alg = (flops, bytes) of the layer for the timer."""
     _need_cuda(X, Wp, bias, out)
     if X.dtype != TORCH_DT[dtype] or Wp.dtype != TORCH_DT[dtype]:
         raise RuntimeError(f"gather_gemm: operand dtype {X.dtype}/{Wp.dtype} does not match engine dtype")
@@ -328,16 +312,6 @@ def gather_gemm(g: GGSpec, X: torch.Tensor, Wp: torch.Tensor, dtype: int, bias: 
         if mx.numel() != Y.numel() or mx.dtype != Y.dtype:
             raise RuntimeError("gather_gemm: mask tensor must be shaped and typed like the output")
         d.mask_x, d.mask_act, d.mask_slope = mx.data_ptr(), mact, mslope
-    if bnb is not None:
-        by, bco, bact, bslope = bnb
-        if want_stats or mask is not None or by.numel() != Y.numel() or by.dtype != Y.dtype or bco.numel() != 4 * g.N:
-            raise RuntimeError("gather_gemm: bnb needs a Y-shaped raw tensor, [4][N] coefficients, no stats / mask")
-        nparts = gather_gemm_bnb_parts(g, X, Wp, dtype)
-        if nparts <= 0:
-            raise RuntimeError("gather_gemm: this launch has no BatchNorm-backward epilogue (probe gather_gemm_bnb_parts)")
-        stats = WS.get("bnbwd", max(nparts, 2048) * 2 * g.N * 4, X.device)
-        d.bnb_y, d.bnb_coeffs, d.bnb_partial = by.data_ptr(), bco.data_ptr(), stats.data_ptr()
-        d.bnb_act, d.bnb_slope, d.bnb_capacity = bact, bslope, max(nparts, 2048)
     wsb = lib.vg_gather_gemm_ws_bytes(byref(d), dtype)
     ws = None
     if wsb > 0:
@@ -347,7 +321,7 @@ def gather_gemm(g: GGSpec, X: torch.Tensor, Wp: torch.Tensor, dtype: int, bias: 
     if TIMER is not None:
         fam = {0: "gather_gemm", 2: "edge", 3: "gather_gemm_fp8"}[lib.vg_gather_gemm_family(byref(d), dtype)]
         tok = TIMER.begin(fam, *(alg or (g.flops(), 0)))
-    if BINDING == "torchops" and bnb is None:      # (the custom-op face has no bnb arguments: that launch goes through ctypes)
+    if BINDING == "torchops":
         torch_ops().gather_gemm(X, Wp, Y, bias, stats, ws if wsb > 0 else None, zero_page(X.device),
                                 mask[0] if mask is not None else None, _gg_geom(d), float(d.act_slope),
                                 float(d.mask_slope), dtype)
@@ -358,11 +332,8 @@ def gather_gemm(g: GGSpec, X: torch.Tensor, Wp: torch.Tensor, dtype: int, bias: 
     return Y, stats, nparts
 
 
-def edge_wgrad(ew: EWSpec, wide: torch.Tensor, narrow: torch.Tensor, dW: torch.Tensor, accumulate: bool, alg=None,
-               pre=None) -> None:
-    """Weight gradient of an edge layer (vg_edge_wgrad): wide [B,WH,WW,C] bf16, narrow [B,NH,NW,8] bf16, dW f32.
-    pre = (scale [C], shift [C], act, slope): `wide` is the RAW output of the layer below; its BatchNorm + activation
-    are applied inside the kernel."""
+def edge_wgrad(ew: EWSpec, wide: torch.Tensor, narrow: torch.Tensor, dW: torch.Tensor, accumulate: bool, alg=None) -> None:
+    """Weight gradient of an edge layer (vg_edge_wgrad): wide [B,WH,WW,C] bf16, narrow [B,NH,NW,8] bf16, dW f32."""
     _need_cuda(wide, narrow, dW)
     if wide.dtype != torch.bfloat16 or narrow.dtype != torch.bfloat16 or dW.dtype != torch.float32:
         raise RuntimeError("edge_wgrad: bf16 operands, float32 gradient")
@@ -372,12 +343,10 @@ def edge_wgrad(ew: EWSpec, wide: torch.Tensor, narrow: torch.Tensor, dW: torch.T
     d = L.EWDesc(Wd=wide.data_ptr(), Nr=narrow.data_ptr(), dW=dW.data_ptr(), ws=0, ws_bytes=0,
                  zeros=zero_page(wide.device).data_ptr(), B=ew.B, WH=ew.WH, WW=ew.WW, C=ew.C, NH=ew.NH, NW=ew.NW, N=ew.N,
                  K=ew.K, S=ew.S, P=ew.P, s_c=ew.s_c, s_n=ew.s_n, accumulate=1 if accumulate else 0)
-    if pre is not None:
-        d.in_scale, d.in_shift, d.in_act, d.in_slope = pre[0].data_ptr(), pre[1].data_ptr(), pre[2], pre[3]
     nbytes = lib.vg_edge_wgrad_ws_bytes(byref(d))
     if nbytes < 0:
         L.check(int(nbytes), "vg_edge_wgrad_ws_bytes")
-    ws = WS.get("wgrad" if _WS_SUFFIX is None else "wgrad" + _WS_SUFFIX, nbytes, wide.device)
+    ws = WS.get("wgrad", nbytes, wide.device)
     d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * 4
     tok = TIMER.begin("wgrad", *(alg or (ew.flops(), 0))) if TIMER is not None else None
     L.check(lib.vg_edge_wgrad(byref(d), L.stream_ptr()), "vg_edge_wgrad")
@@ -396,11 +365,9 @@ def cast_fp8(x: torch.Tensor, shift: int = 0, out: torch.Tensor = None) -> torch
 
 
 def tnconv(tn: TNSpec, X: torch.Tensor, Wp: torch.Tensor, want_nhwc: bool = True, want_nchw: bool = False,
-           act: int = 0, noise=None, sigma: float = 0.0, out_nhwc: torch.Tensor = None, alg=None, pre=None):
+           act: int = 0, noise=None, sigma: float = 0.0, out_nhwc: torch.Tensor = None, alg=None):
     """Narrow-N transposed convolution (vg_tnconv) -> (Y NHWC bf16 [B,OH,OW,OC] or None, Y NCHW f32 or None).
-    noise: None, an NCHW f32 tensor [B,N,OH,OW] or a NoiseDraw; with noise, Y = act(.) + sigma*noise.
-    pre = (scale [C], shift [C], act, slope): X is the RAW output of the layer below; its BatchNorm + activation are
-    applied inside the kernel (no separate vg_bn_act_forward pass, no activated copy of X)."""
+    noise: None, an NCHW f32 tensor [B,N,OH,OW] or a NoiseDraw; with noise, Y = act(.) + sigma*noise."""
     rng = isinstance(noise, NoiseDraw)
     _need_cuda(X, Wp, None if rng else noise, out_nhwc)
     if X.dtype != torch.bfloat16 or Wp.dtype != torch.bfloat16:
@@ -421,8 +388,6 @@ def tnconv(tn: TNSpec, X: torch.Tensor, Wp: torch.Tensor, want_nhwc: bool = True
                  rng=noise.state.data_ptr() if rng else 0, draw=noise.draw if rng else 0, sigma=sigma,
                  B=tn.B, IH=tn.IH, IW=tn.IW, C=tn.C, N=tn.N, K=tn.K, S=tn.S, P=tn.P, OH=tn.OH, OW=tn.OW, OC=tn.OC,
                  Wpitch=tn.Wpitch, act=act)
-    if pre is not None:
-        d.in_scale, d.in_shift, d.in_act, d.in_slope = pre[0].data_ptr(), pre[1].data_ptr(), pre[2], pre[3]
     tok = TIMER.begin("edge", *(alg or (tn.flops(), 0))) if TIMER is not None else None
     L.check(L.load().vg_tnconv(byref(d), L.stream_ptr()), "vg_tnconv")
     if tok is not None:
@@ -446,7 +411,7 @@ def wgrad(wg: WGSpec, P: torch.Tensor, Q: torch.Tensor, dW: torch.Tensor, accumu
     if nbytes < 0:
         L.check(int(nbytes), "vg_wgrad_ws_bytes")
     # the slab workspace is shared by all launches of one stream; work forked onto another stream gets its own
-    ws = WS.get("wgrad" if _WS_SUFFIX is None else "wgrad" + _WS_SUFFIX, nbytes, P.device)
+    ws = WS.get("wgrad", nbytes, P.device)
     d.ws = ws.data_ptr()
     d.ws_bytes = ws.numel() * 4
     tok = TIMER.begin("wgrad", *(alg or (0, 0))) if TIMER is not None else None
@@ -553,27 +518,18 @@ def channel_stats(x, rows, C, dtype):
     return stats, n.value
 
 
-def bn_act_backward(x, dy, coeffs, rows, C, count, gamma, act, slope, dgamma, dbeta, accumulate, dtype, sync=None,
-                    partial=None):
-    """Full BN(+act) backward: returns dx (gradient w.r.t. the raw conv output).  coeffs: [groups][4][C].
-    partial = (slabs [n][2][C], n): the (sum dz | sum dz*xhat) partials already produced by the data-gradient kernel that
-    wrote dy (gather_gemm(..., bnb=...)); the reduce pass is skipped (groups == 1, no sync)."""
+def bn_act_backward(x, dy, coeffs, rows, C, count, gamma, act, slope, dgamma, dbeta, accumulate, dtype, sync=None):
+    """Full BN(+act) backward: returns dx (gradient w.r.t. the raw conv output).  coeffs: [groups][4][C]."""
     _need_cuda(x, dy, coeffs)
     lib = L.load()
     groups = coeffs.shape[0]
     n = c_int(0)
     cap = 2048
-    if partial is not None:
-        if groups != 1 or sync is not None:
-            raise RuntimeError("bn_act_backward: precomputed partials need groups == 1 and no SyncBN")
-        partial, nn = partial
-        n = c_int(nn)
-    else:
-        partial = WS.get("bnbwd", cap * 2 * C * 4, x.device)
-        L.check(lib.vg_bn_act_backward_reduce(x.data_ptr(), dy.data_ptr(), coeffs[0, 2].data_ptr(),
-                                              coeffs[0, 3].data_ptr(), coeffs[0, 0].data_ptr(), coeffs[0, 1].data_ptr(),
-                                              rows, C, act, slope, partial.data_ptr(), cap, byref(n), groups, 4 * C,
-                                              dtype, L.stream_ptr()), "vg_bn_act_backward_reduce")
+    partial = WS.get("bnbwd", cap * 2 * C * 4, x.device)
+    L.check(lib.vg_bn_act_backward_reduce(x.data_ptr(), dy.data_ptr(), coeffs[0, 2].data_ptr(),
+                                          coeffs[0, 3].data_ptr(), coeffs[0, 0].data_ptr(), coeffs[0, 1].data_ptr(),
+                                          rows, C, act, slope, partial.data_ptr(), cap, byref(n), groups, 4 * C,
+                                          dtype, L.stream_ptr()), "vg_bn_act_backward_reduce")
     if sync is None and x.shape[-1] == C and \
             lib.vg_bn_finalize_act_forward_supported(n.value, groups, C, rows, dtype):
         # small layer: finalize + apply in one launch (bn_act.hip bn_bwd_fin_apply_kernel); n = partial rows PER GROUP
@@ -619,7 +575,7 @@ def act_backward(x, dy, act, slope, dtype):
 
 def bias_grad(dy, rows, C, NC, dbias, accumulate, dtype):
     cap = 1024
-    ws = WS.get("biasgrad" if _WS_SUFFIX is None else "biasgrad" + _WS_SUFFIX, cap * 2 * C * 4, dy.device)
+    ws = WS.get("biasgrad", cap * 2 * C * 4, dy.device)
     L.check(L.load().vg_bias_grad(dy.data_ptr(), rows, C, NC, dbias.data_ptr(), 1 if accumulate else 0,
                                   ws.data_ptr(), cap, dtype, L.stream_ptr()), "vg_bias_grad")
 

@@ -28,11 +28,20 @@ class _Graphed:
     _opts: Sequence = ()
 
     def step_graphed(self, *tensors, **scalars):
+        # Draws that are not injected come from the per-device default NoiseStream, whose STATE BUFFER the captured
+        # vg_rng_advance / vg_randn launches point at.  utils.configure_seed() (ops.reset_noise) drops that stream: the
+        # graph must then be re-captured against the new one -- the buffer's address is part of the key, and the
+        # trainer holds a reference to the stream it captured so the old buffer cannot be recycled under a replay.
+        noise = None
+        if any(t is None for t in tensors):
+            dev = next(t for t in tensors if t is not None).device
+            noise = ops.default_noise(dev)
         key = (tuple(None if t is None else tuple(t.shape) for t in tensors), tuple(sorted(scalars.items())),
-               tuple(n.training for n in self._nets))
+               tuple(n.training for n in self._nets), None if noise is None else noise.state.data_ptr())
+        self._gnoise = noise
         st = getattr(self, "_gstate", None)
         if st is not None and st[0] == key:
-            _, graph, sin, sout, dticks, dsteps = st
+            _, graph, sin, sout, dticks, dsteps = st[:6]
             for s, t in zip(sin, tensors):
                 if s is not None:
                     s.copy_(t)
@@ -63,7 +72,7 @@ class _Graphed:
             n._engine.pending_bn_ticks = t
         for o, s in zip(self._opts, steps):
             o.steps = s
-        self._gstate = (key, graph, sin, sout, dticks, dsteps)
+        self._gstate = (key, graph, sin, sout, dticks, dsteps, noise)   # noise: keeps the captured state buffer alive
         graph.replay()
         self._bump(dticks, dsteps)
         return sout

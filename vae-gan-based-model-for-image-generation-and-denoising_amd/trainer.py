@@ -14,9 +14,7 @@ import torch
 
 from . import geometry as G
 from . import ops
-from .engine import GradSink, no_gc_while_capturing, side_stream
-
-_SIDE_INLINE = os.environ.get("VG_SIDE_INLINE", "0") == "1"   # diagnostic for VG_OVERLAP: replay the side graph in order
+from .engine import GradSink, no_gc_while_capturing
 
 LOSS_NAMES = ("recon_loss", "kl_loss", "g_loss_adv", "d_loss_1", "d_loss_2")
 
@@ -63,29 +61,13 @@ class VAEGANTrainer:
             raise ValueError("encoder / decoder / discriminator must share one engine dtype")
         self.dt = dts.pop()
         self.latent = encoder.latent_dim
-        # Opt-in experiment (VG_OVERLAP_E=1): run the Generator's weight gradients beside the Encoder's backward on a
-        # second stream.  MEASURED SLOWER on MI355X (S=64, B=128, graph replay, interleaved A/B: 3.156 vs 3.079 ms):
-        # like the per-layer side-stream weight gradients of round 1, concurrent grids cost more in lost L2/LDS
-        # residency and queueing than the latency-bound Encoder chain leaves idle.
-        self.overlap_encoder_backward = os.environ.get("VG_OVERLAP_E", "0") == "1"
-        # VG_OVERLAP (opt-in bit mask; single-GPU schedule only, i.e. reducer is None): work that nothing before the end
-        # of the iteration waits for runs on the side stream beside the Encoder's backward, a chain of 38 dependent
-        # kernels of 2-18 us each that leaves most of the chip idle:
-        #   1  the Generator's Adam step and the re-pack of its GEMM operands (otherwise the first thing the NEXT
-        #      iteration's Generator forward does),
-        #   2  the (dead, vaegan_code.py:133) Discriminator weight gradients of the generator-loss pass as well.
-        # Under hipGraph replay the side work is its OWN graph launched on the side stream between two segments of the
-        # main graph.  Bit-identical to the serial schedule and MEASURED SLOWER (+105...+150 us; a
-        # fork inside ONE captured graph costs even more; each extra graph boundary ~29 us; the wide grids of the side
-        # stream delay every kernel of the latency-bound chain they were meant to hide under).
-        self.overlap = int(os.environ.get("VG_OVERLAP", "0"))
         self.losses = None
         self.noise = None               # ops.NoiseStream for the in-kernel randn_like draws (created on first use)
+        self._noise_pinned_seed = None  # torch device seed at the time a checkpoint's noise stream was restored
         self._bucket_plans = {}
         self._graph = None              # (key, [hipGraph segments], [collectives between them], static in, static out)
         self._warm_key = None
         self._cut_hook = None           # set while capturing: splits the iteration into graph segments
-        self._side_hook = None          # set while capturing: side work becomes a graph of its own
 
     def train(self):
         self.E.train(), self.G.train(), self.D.train()                                         # :56-58
@@ -95,6 +77,9 @@ class VAEGANTrainer:
         torch.cuda.manual_seed) keys it, as it keys torch.randn_like in the reference; re-seeding torch starts a new
         stream (and invalidates a captured graph, which holds the old state buffer)."""
         seed = torch.cuda.initial_seed()
+        if self.noise is not None and self._noise_pinned_seed == seed:
+            return self.noise           # restored from a checkpoint: pinned until torch is explicitly re-seeded
+        self._noise_pinned_seed = None
         if self.noise is None or self.noise.seed != seed:
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("noise stream (re)seeded during graph capture")
@@ -109,7 +94,7 @@ class VAEGANTrainer:
         opts = tuple((o.lr, o.betas, o.eps, o.grad_scale, o.flat_p.data_ptr()) for o in (self.opt_E, self.opt_G, self.opt_D))
         return (tuple(real.shape), float(self.alpha_kl * min(1.0, epoch / 50)), inject, self.E.training, self.G.training,
                 self.D.training, self.alpha_adv, self.sigma, self.real_label, self.fake_label, self.d_iters,
-                self.elide_dead_grads, self.group_d_passes, id(self.reducer), self.sync_bn, opts, self.overlap,
+                self.elide_dead_grads, self.group_d_passes, id(self.reducer), self.sync_bn, opts,
                 None if self.noise is None or inject else self.noise.state.data_ptr())
 
     # ---- data-parallel gradient hand-off (ddp.GradReducer) -------------------------------------------------------
@@ -164,22 +149,6 @@ class VAEGANTrainer:
         else:
             self._cut_hook(collective)
 
-    def _side(self, work, dev) -> None:
-        """Run `work` (launches nothing before the end of the iteration depends on) beside what follows on the current
-        stream.  Eager: fork onto the side stream.  While capturing: `work` becomes its own hipGraph, replayed on the side
-        stream between two segments of the main graph."""
-        if self._side_hook is not None:
-            self._side_hook(work)
-            return
-        side = side_stream(dev)
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            work()
-
-    def _side_join(self, dev) -> None:
-        if self._side_hook is None:         # (a replay joins after its last segment)
-            torch.cuda.current_stream().wait_stream(side_stream(dev))
-
     def train_step(self, real: torch.Tensor, epoch: int, eps_z: Optional[torch.Tensor] = None,
                    eps_real: Optional[torch.Tensor] = None, eps_recon: Optional[torch.Tensor] = None) -> torch.Tensor:
         """One iteration.  Returns a device tensor [recon_loss, kl_loss, g_loss_adv, d_loss_1, d_loss_2]."""
@@ -197,10 +166,11 @@ class VAEGANTrainer:
             eps_z = noise.draw(0) if eps_z is None else eps_z
             eps_real = noise.draw(1) if eps_real is None else eps_real
             eps_recon = noise.draw(2) if eps_recon is None else eps_recon
-        losses = torch.empty(8, dtype=torch.float32, device=dev)     # every slot read later is written (not accumulated) first
+        # slots 0..4 are written (not accumulated) below when d_iters >= 2; with d_iters = 1 slot 4 (d_loss_2) is never
+        # written and with d_iters > 2 it holds the LAST iteration's loss -- zeroed so that it reads 0, not stale memory
+        losses = ops.zeros_f32(8, dev)
         sink = GradSink(direct=True)
 
-        overlap = self.overlap if self.reducer is None else 0
         # ---- Encode / reparameterise / decode (:74-83) ----
         mulv, ctxE = E.engine_forward(real)
         ZP = G.padc(Gn.nz, dt)
@@ -252,41 +222,17 @@ class VAEGANTrainer:
         # ---- backward of total = recon + a_kl*min(1,epoch/50)*kl + a_adv*adv, then E and G steps (:131-135) ----
         self.opt_E.zero_grad(memset=False)
         self.opt_G.zero_grad(memset=False)
-        dead = [] if (overlap & 2 and not self.elide_dead_grads) else None
-        d_noisy = D._engine.backward(c_adv, dp_adv, True, sink, param_grads=not self.elide_dead_grads, defer=dead)
+        d_noisy = D._engine.backward(c_adv, dp_adv, True, sink, param_grads=not self.elide_dead_grads)
         # d total / d recon = d MSE + d adv through the instance-noise add (:92), then through tanh: one pass
         d_pre = ops.nchw_grad_add_to_nhwc(d_recon, d_noisy, recon, G.padc(Gn.nc, dt), dt)
-        # (opt-in, see __init__) the Generator's weight gradients held back and launched on a second stream beside the
-        # Encoder's backward
-        deferred = [] if (self.reducer is None and self.overlap_encoder_backward) else None
-        dz = Gn._engine.backward(ctxG, d_pre, True, sink, on_grads=self._grad_hook(self.opt_G, Gn), defer=deferred)
+        dz = Gn._engine.backward(ctxG, d_pre, True, sink, on_grads=self._grad_hook(self.opt_G, Gn))
         self._finish_reduce(self.opt_G, Gn, wait=False)       # G's last bucket overlaps the encoder's backward
-        Gn._engine.run_deferred(deferred, dev)
-        if overlap:                         # the Generator's gradients are complete: the rest of its update leaves the critical path
-            def tail():
-                if overlap & 1:
-                    self.opt_G.step()
-                    Gn._engine._ensure_packed()
-                if dead:
-                    ops.set_ws_suffix(".side")
-                    try:
-                        for fn in dead:
-                            fn()
-                    finally:
-                        ops.set_ws_suffix(None)
-            self._side(tail, dev)
         kl_w = self.alpha_kl * min(1.0, epoch / 50)                                            # :117
         dmulv = ops.reparam_kl_backward(mulv, lvc, eps_z, dz, kl_w / B, L, dt)
         E._engine.backward(ctxE, dmulv.view(B, 1, 1, -1), False, sink, on_grads=self._grad_hook(self.opt_E, E))
-        Gn._engine.join_deferred(deferred, dev)
         self._finish_reduce(self.opt_E, E, also_wait=(self.opt_G,))
         self.opt_E.step()
-        if not overlap & 1:
-            self.opt_G.step()
-        if overlap:
-            self._side_join(dev)
-            if dead:
-                dead.clear()                # the closures kept the operands alive until the join
+        self.opt_G.step()
         self.losses = losses
         return losses
 
@@ -317,8 +263,6 @@ class VAEGANTrainer:
         key = self._capture_key(real, epoch, inject)
         if self._graph is not None and self._graph[0] == key:
             _, graphs, cuts, sin, sout = self._graph
-            if self.overlap & 1 and self.reducer is None:
-                self.G._engine._ensure_packed()    # no-op unless someone changed the Generator's weights between replays
             if real.data_ptr() != sin[0].data_ptr():    # a batch assembled in graph_input() needs no copy
                 sin[0].copy_(real)
             if inject:
@@ -334,8 +278,6 @@ class VAEGANTrainer:
         sin = [real.clone()] + ([eps_z.clone(), eps_real.clone(), eps_recon.clone()] if inject else [None] * 3)
         for eng in (self.E._engine, self.G._engine, self.D._engine):
             eng.invalidate()                       # the captured sequence must contain the operand re-packs
-        if self.overlap & 1 and self.reducer is None:
-            self.G._engine._ensure_packed()        # ... the Generator's sits at the END of the iteration (side graph): start fresh
         # Nothing of torch.distributed may be in flight while a stream is capturing: c10d's watchdog thread polls
         # unfinished collectives with hipEventQuery, which is illegal next to a capture (the abort recorded in round 1).
         # Structural guard rather than luck: wait for every collective this trainer launched, drain the device, and
@@ -365,19 +307,6 @@ class VAEGANTrainer:
             cuts.append(collective)
             begin()
 
-        side_pool = torch.cuda.graph_pool_handle()   # side graphs run beside the next segment: they share no memory with it
-
-        def side_work(work):                       # close this segment, capture `work` as a graph of its own, open the next
-            graphs[-1].capture_end()
-            g = torch.cuda.CUDAGraph()
-            g.capture_begin(pool=side_pool, capture_error_mode="thread_local")
-            graphs.append(g)
-            work()
-            g.capture_end()
-            graphs.pop()
-            cuts.append(("side", g))
-            begin()
-
         def restore_host_counters():               # capture only records: undo the host-side counter changes it made
             for m, t in zip((self.E, self.G, self.D), ticks):
                 m._engine.pending_bn_ticks = t
@@ -386,7 +315,6 @@ class VAEGANTrainer:
 
         with no_gc_while_capturing(), torch.cuda.stream(cap):
             self._cut_hook = cut
-            self._side_hook = side_work if self.reducer is None else None
             try:
                 begin()
                 sout = self.train_step(sin[0], epoch, sin[1], sin[2], sin[3])
@@ -405,7 +333,6 @@ class VAEGANTrainer:
                 raise
             finally:
                 self._cut_hook = None
-                self._side_hook = None
         torch.cuda.current_stream().wait_stream(cap)
         restore_host_counters()                    # then replay for real
         self._graph = (key, graphs, cuts, sin, sout)
@@ -416,21 +343,10 @@ class VAEGANTrainer:
 
     @staticmethod
     def _replay(graphs, cuts) -> None:
-        side = None
         for i, g in enumerate(graphs):
             g.replay()
             if i < len(cuts):
-                if isinstance(cuts[i], tuple) and _SIDE_INLINE:
-                    cuts[i][1].replay()             # diagnostic: same segments, no concurrency
-                elif isinstance(cuts[i], tuple):    # ("side", graph): forked here, joined after the last segment
-                    side = side_stream(torch.device("cuda", torch.cuda.current_device()))
-                    side.wait_stream(torch.cuda.current_stream())
-                    with torch.cuda.stream(side):
-                        cuts[i][1].replay()
-                else:
-                    cuts[i]()
-        if side is not None:
-            torch.cuda.current_stream().wait_stream(side)
+                cuts[i]()                       # the collective that separates segment i from segment i + 1
 
     def _advance_host_counters(self) -> None:
         """What one iteration does to host-side mirrors: BatchNorm forward counts (E 1, G 1, D 2*d_iters+1) and
@@ -472,6 +388,10 @@ class VAEGANTrainer:
                 self._graph = None
             self.noise.seed = int(st[0])
             self.noise.set_state(st)
+            # The restored stream (its seed AND iteration counter) stays in use although the resuming process's torch
+            # seed differs from the saved one (or the saved seed was >= 2^63 and is stored masked): only an explicit
+            # re-seed of torch AFTER this point (utils.configure_seed / torch.cuda.manual_seed) starts a new stream.
+            self._noise_pinned_seed = torch.cuda.initial_seed()
 
     def save_checkpoint(self, path: str, **extra) -> None:
         """extra: plain numbers / strings / tensors stored next to the state (e.g. epoch=...)."""
