@@ -60,7 +60,10 @@ def main():
                "grad_E": (torch.cat([p.grad.flatten() for p in e.parameters()]) / world).cpu().numpy(),
                "grad_G": (torch.cat([p.grad.flatten() for p in g.parameters()]) / world).cpu().numpy(),
                "par_E": oE.flat_p.cpu().numpy(), "par_G": oG.flat_p.cpu().numpy(), "par_D": oD.flat_p.cpu().numpy(),
-               "stat_collectives": np.array(red.stat_collectives)}
+               "stat_collectives": np.array(red.stat_collectives), "collectives": np.array(red.collectives),
+               # buckets per optimizer (E, G, D) as the real GradReducer planned them, and hipGraph segments of a replay
+               "buckets": np.array([len(red.buckets(o)) for o in (oE, oG, oD)]),
+               "segments": np.array(0 if tr._graph is None else len(tr._graph[1]))}
         for name, net in (("E", e), ("G", g), ("D", d)):
             for k, v in net.state_dict().items():
                 if "running" in k or "num_batches" in k:

@@ -77,7 +77,7 @@ def _worker(rank, world, port, out_dir):
         gen = torch.Generator().manual_seed(100 + rank)
         opt3.flat_g.copy_(torch.randn(n3, generator=gen))
         opt3_flat.flat_g.copy_(opt3.flat_g)
-        red3 = ddp.GradReducer(bucket_bytes=4 * 1500)
+        red3 = ddp.GradReducer(bucket_bytes=4 * 1500, max_buckets=0)        # every bucket the byte rule cuts
         plan = red3.plan(opt3, ready=[0, 1, 2, 3, 4])
         launched = []
         for ev in (4, 3, 2, 1, 0):                          # backward order
@@ -144,6 +144,51 @@ def test_bucket_plan_covers_the_buffer_in_reverse_layer_order():
     # fc_logvar homed behind fc_mu (offsets not in parameter order)
     plan = ddp.plan_buckets([0, 200, 100, 300], [100, 100, 100, 100], [4, 4, 4, 4], 400, 1 << 30)
     assert plan == [(0, 400, 4)]
+
+
+def _layout(sizes):
+    offs, o = [], 0
+    for k in sizes:
+        offs.append(o)
+        o += (k + 3) // 4 * 4
+    return offs, o
+
+
+def test_bounded_bucket_plans_of_the_three_networks_at_S64():
+    """The documented S=64 bucket layout (ddp.py module docstring), pinned: with the default bound
+    (a tail under 8 MB glued on, at most 2 buckets per optimizer) D is ONE bucket, G is {G5..G2 | G1 + G0}, E is one --
+    5 collectives = 5 hipGraph cuts per step (D steps twice); the unbounded byte rule gives the 9 of round 2."""
+    ddp = importlib.import_module(PKG + ".ddp")
+    # Discriminator: conv0, conv1+bn, conv2+bn, conv3+bn, head
+    dsz = [3072, 131072, 128, 128, 524288, 256, 256, 2097152, 512, 512, 8192]
+    drd = [0, 1, 1, 1, 2, 2, 2, 3, 3, 3, 4]
+    # Generator: convT0+bn ... convT4+bn, convT5   (gan_code.py:21-49 under size rule A0)
+    gsz = [1638400, 1024, 1024, 8388608, 512, 512, 2097152, 256, 256, 524288, 128, 128, 131072, 64, 64, 1728]
+    grd = [0, 0, 0, 1, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 4, 5]
+    # Encoder: 4 x (conv weight, conv bias, bn weight, bn bias), fc_mu, fc_logvar (main_vae.py:34-58)
+    esz = [1536, 32, 32, 32, 32768, 64, 64, 64, 131072, 128, 128, 128, 524288, 256, 256, 256, 102400, 100, 102400, 100]
+    erd = [0] * 4 + [1] * 4 + [2] * 4 + [3] * 4 + [4] * 4
+    plans = {}
+    for name, sizes, ready in (("D", dsz, drd), ("G", gsz, grd), ("E", esz, erd)):
+        offs, total = _layout(sizes)
+        free = ddp.plan_buckets(offs, sizes, ready, total, 8 << 20)
+        plan = ddp.plan_buckets(offs, sizes, ready, total, 8 << 20, ddp.DEFAULT_MAX_BUCKETS)
+        plans[name] = (offs, total, free, plan)
+        covered = sorted((lo, hi) for lo, hi, _ in plan)
+        assert covered[0][0] == 0 and covered[-1][1] == total and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+        for lo, hi, ev in plan:
+            assert ev == min(ready[i] for i in range(len(sizes)) if lo <= offs[i] < hi)
+        assert [ev for _, _, ev in plan] == sorted((ev for _, _, ev in plan), reverse=True)
+    offs, total, free, plan = plans["D"]
+    assert len(free) == 2 and plan == [(0, total, 0)]
+    offs, total, free, plan = plans["G"]
+    assert [ev for _, _, ev in free] == [2, 1, 0]                          # {G5..G2} | {G1} | {G0}
+    assert plan == [(offs[6], total, 2), (0, offs[6], 0)]                   # {G5..G2} leaves first, {G1 + G0} at the end
+    assert 10e6 < (total - offs[6]) * 4 < 12e6 and 39e6 < offs[6] * 4 < 41e6
+    offs, total, free, plan = plans["E"]
+    assert plan == free == [(0, total, 0)]
+    cuts = 2 * len(plans["D"][3]) + len(plans["G"][3]) + len(plans["E"][3])
+    assert cuts == 5 and 2 * len(plans["D"][2]) + len(plans["G"][2]) + len(plans["E"][2]) == 8
 
 
 def test_reducer_requires_process_group():

@@ -187,6 +187,13 @@ def test_single_rank_over_rccl_equals_single_process(tmp_path, sync_bn, graph):
     assert np.isfinite(r0["losses"]).all() and np.isfinite(r0["par_G"]).all()
     if sync_bn:
         assert int(r0["stat_collectives"]) > 0
+    else:
+        # the default bucket bound (ddp.py: tail glued on, <= 2 buckets per optimizer): E 1, G 2, D 1 -> 5 gradient
+        # collectives = 5 graph cuts = 6 segments per iteration (round 2: 9 cuts)
+        assert list(r0["buckets"]) == [1, 2, 1]
+        assert int(r0["collectives"]) == 5 * steps
+        if graph:
+            assert int(r0["segments"]) == 6
     for k in one:
         if k.startswith("buf_") and "num_batches" in k:
             assert int(r0[k]) == int(one[k]), k

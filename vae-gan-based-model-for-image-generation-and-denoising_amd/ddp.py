@@ -10,10 +10,16 @@ Design for the MI355X node (8 GPUs, fully connected, 7 x ~153 GB/s links each):
     than latency-bound on point-to-point xGMI links, small enough that the first one leaves early).  A bucket's
     all-reduce is launched ASYNCHRONOUSLY the moment its last weight gradient has been enqueued
     (trainer.py cuts its hipGraph there) and runs on RCCL's stream under the rest of the backward pass;
-    the optimizer step waits for its buckets only.  S=64 sizes: D = {D3+head 8.4 MB | D2..D0 2.8 MB},
-    G = {G5..G2 10.7 MB | G1 33.6 MB | G0 6.6 MB}, E = {3.6 MB}; per step and GPU 77 MB in 9 collectives
-    (D twice).  A bucket is a contiguous slice of the flat buffer: reducing the slices is bit-identical to
-    reducing the whole buffer (elementwise sums; tests/test_ddp_gloo.py).
+    the optimizer step waits for its buckets only.
+  * every bucket launch is a hipGraph CUT, and a cut costs ~29 us of idle GPU (a replayed graph starts ~27 us after
+    its predecessor ends: DESIGN.md section 9), so the number of buckets is bounded: a tail smaller than `bucket_bytes`
+    is glued to the bucket before it (it would be latency-bound anyway) and at most `max_buckets` (default 2) buckets
+    are kept per optimizer, merging from the FRONT so that what is left for the end of the backward pass stays small.
+    S=64: D = {11.2 MB} (twice per step), G = {G5..G2 11.0 MB | G1+G0 40.2 MB}, E = {3.6 MB}: 77 MB per step and GPU
+    in 5 collectives = 5 cuts (round 2: 9).  A bucket is a contiguous slice of the flat buffer: reducing the slices is
+    bit-identical to reducing the whole buffer (elementwise sums; tests/test_ddp_gloo.py).
+    MEASURED ON HARDWARE: the overlap itself never was -- no 8-GPU node has been available to the build in rounds 1-3
+    (SCALE_r01/r02 are skip records); on one GPU the RCCL calls run with a single rank (tests/test_gpu_ddp.py).
 
 BatchNorm statistics stay per replica by default (standard DDP semantics, throughput mode).  Loss
 normalisers are per-replica means; with equal per-replica batches the averaged gradient equals the
@@ -31,15 +37,20 @@ import torch.distributed as dist
 DEFAULT_BUCKET_BYTES = 8 << 20
 
 
+DEFAULT_MAX_BUCKETS = 2
+
+
 def plan_buckets(offsets: Sequence[int], numels: Sequence[int], ready: Sequence[int], total: int,
-                 bucket_bytes: int = DEFAULT_BUCKET_BYTES) -> List[Tuple[int, int, int]]:
+                 bucket_bytes: int = DEFAULT_BUCKET_BYTES, max_buckets: int = 0) -> List[Tuple[int, int, int]]:
     """Cut a flat gradient buffer of `total` floats into contiguous buckets.
 
     offsets/numels: placement of every parameter in the buffer; ready[i]: the backward pass finishes parameter
     i's gradient at event ready[i], events counting DOWN (the stage index of the layer: the last layer's gradients
     come first).  Returns [(lo, hi, event)] in launch order: bucket (lo, hi) is complete once event `event` -- the
     smallest event of any parameter inside -- has happened.  Every float of [0, total) is in exactly one bucket
-    (alignment padding rides along)."""
+    (alignment padding rides along).  max_buckets > 0 bounds the number of buckets (= hipGraph cuts): a tail smaller
+    than bucket_bytes is glued to the bucket before it, then the first buckets (in launch order) are merged until at
+    most max_buckets are left; 0 keeps every bucket the byte rule produces."""
     spans = sorted((offsets[i], offsets[i] + (numels[i] + 3) // 4 * 4, ready[i]) for i in range(len(offsets)))
     # walk the buffer from its END (last layers live there, up to local re-ordering) and close a bucket whenever
     # enough bytes have gathered; the bucket's event is the earliest layer it contains
@@ -58,17 +69,28 @@ def plan_buckets(offsets: Sequence[int], numels: Sequence[int], ready: Sequence[
             buckets.append((0, hi, ev))
     # launch order = by event, descending; a later-closing bucket must never wait on an earlier event than it reports
     buckets.sort(key=lambda b: (-b[2], -b[0]))
+    if max_buckets > 0:
+        def glue(a, b):                                   # two buckets adjacent in the buffer -> one (the later event)
+            assert a[0] == b[1] or b[0] == a[1], "buckets to merge must be adjacent slices"
+            return (min(a[0], b[0]), max(a[1], b[1]), min(a[2], b[2]))
+        if len(buckets) > 1 and (buckets[-1][1] - buckets[-1][0]) * 4 < bucket_bytes:
+            tail = buckets.pop()
+            buckets.append(glue(buckets.pop(), tail))
+        while len(buckets) > max_buckets:
+            first = buckets.pop(0)
+            buckets[0] = glue(first, buckets[0])
     return buckets
 
 
 class GradReducer:
-    def __init__(self, process_group=None, bucket_bytes: int = DEFAULT_BUCKET_BYTES):
+    def __init__(self, process_group=None, bucket_bytes: int = DEFAULT_BUCKET_BYTES, max_buckets: int = DEFAULT_MAX_BUCKETS):
         if not dist.is_available() or not dist.is_initialized():
             raise RuntimeError("GradReducer needs an initialised torch.distributed process group "
                                "(backend 'nccl' = RCCL on the MI355X node, 'gloo' for CPU tests)")
         self.group = process_group
         self.world = dist.get_world_size(process_group)
         self.bucket_bytes = int(bucket_bytes)
+        self.max_buckets = int(max_buckets)          # per optimizer; every bucket is one hipGraph cut (0: no bound)
         self._pending: Dict[int, list] = {}          # id(opt) -> [Work, ...]
         self._buckets: Dict[int, List[Tuple[int, int, int]]] = {}
         self.bytes_reduced = 0
@@ -83,7 +105,8 @@ class GradReducer:
     # ---- bucketed, overlapped reduction -------------------------------------------------------------------------
     def plan(self, opt, ready: Sequence[int]) -> List[Tuple[int, int, int]]:
         """ready[i] = backward event (stage index, counting down) that completes opt.params[i]'s gradient."""
-        b = plan_buckets(opt.offsets, [p.numel() for p in opt.params], ready, opt.flat_g.numel(), self.bucket_bytes)
+        b = plan_buckets(opt.offsets, [p.numel() for p in opt.params], ready, opt.flat_g.numel(), self.bucket_bytes,
+                         self.max_buckets)
         self._buckets[id(opt)] = b
         return b
 
