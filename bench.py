@@ -37,13 +37,27 @@ PEAK = {"fp32": 157.3, "bf16": 2500.0, "fp8": 5000.0}          # dense MFMA TFLO
 def pmc_traffic(dtype):
     """(bytes per gather-GEMM launch, source file) from the newest committed PMC summary
     (profiles/rNN_<dtype>_pmc_traffic.json): measured offline by separate rocprofv3 --pmc passes, not by this run."""
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         f = os.path.join(ROOT, "profiles", f"{rnd}_{dtype}_pmc_traffic.json")
         try:
             return round(json.load(open(f))["families"]["gather_gemm"]["hbm_bytes_per_launch"]), os.path.relpath(f, ROOT)
         except Exception:
             continue
     return None, None
+
+
+def pmc_mfma_busy(dtype):
+    """(MFMA-busy fraction of the gather-GEMM family, of the whole run, source file) from the newest committed
+    rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE pass (profiles/rNN_<dtype>_mfma_busy.json, made by
+    profiles/summarize_mfma.py): measured offline by that separate pass, not by this run."""
+    for rnd in ("r03",):
+        f = os.path.join(ROOT, "profiles", f"{rnd}_{dtype}_mfma_busy.json")
+        try:
+            j = json.load(open(f))
+            return j["families"]["gather_gemm"]["mfma_busy_frac"], j["whole_run"]["mfma_busy_frac"], os.path.relpath(f, ROOT)
+        except Exception:
+            continue
+    return None, None, None
 
 
 def cpu_info():
@@ -155,6 +169,25 @@ def elided_path(V, S, B, dev, dtype, inputs, steps=20):
     dt = time_steps(lambda: tr.train_step_graphed(inputs[0], 60), 4, steps)
     return {"value": round(B / dt, 1), "unit": "images/sec", "ms_per_step": round(dt * 1e3, 3), "steps": steps,
             "mode": "train_step_graphed(elide_dead_grads=True)"}
+
+
+def denoise_path(V, S, B, dev, dtype, inputs, steps=20):
+    """BASELINE configs[3]: the denoising evaluation forward of vaegan_code.py:147-171 at the bench size --
+    eval-mode Encoder -> reparameterise -> Generator on clamp(img + 0.2 * eps, -1, 1), MSE + KL, PSNR and SSIM, noise
+    drawn on the device; the two host reads of denoise_eval (losses, SSIM) are inside the timed region, as the
+    reference's .item() calls are."""
+    e, g, _ = build_models(V, S, "bf16" if dtype == "fp8" else dtype, dev)
+    e.eval(), g.eval()
+    res = {}
+
+    def step():
+        res.update(V.denoise_eval(e, g, inputs[0], sigma=0.2))
+
+    dt = time_steps(step, 3, steps)
+    return {"dtype": {"fp32": "f32", "bf16": "bf16", "fp8": "bf16"}[dtype], "value": round(B / dt, 1), "unit": "images/sec",
+            "ms_per_batch": round(dt * 1e3, 3), "steps": steps, "sigma": 0.2,
+            "psnr_db": round(res["psnr"], 3), "ssim": round(res["ssim"], 4),
+            "mode": "denoise_eval (eval-mode E -> reparam -> G, MSE, KL, PSNR, SSIM; eager launches, 2 host reads per batch)"}
 
 
 def dropin_path(V, S, B, dev, dtype, inputs, steps=10):
@@ -346,6 +379,7 @@ def main():
     gg = fam.get("gather_gemm", dict(launches=0, ms=1e-9, flops=0, bytes=0))
     wg = fam.get("wgrad", dict(launches=0, ms=1e-9, flops=0, bytes=0))
     ed = fam.get("edge", dict(launches=0, ms=0.0, flops=0, bytes=0))
+    bn = fam.get("bn", dict(launches=0, ms=0.0, flops=0, bytes=0))
     ach = gg["flops"] / (gg["ms"] * 1e-3) / 1e12
     traffic, traffic_src = pmc_traffic(args.dtype)
     roofline = {"bound": "mfma", "kernel": "gg_kernel (gather-GEMM: conv/convT/linear fprop + dgrad)",
@@ -368,6 +402,13 @@ def main():
                           "launches_per_step": wg["launches"] // args.steps,
                           "share_of_step": round(wg["ms"] / args.steps / ms, 3)},
                 "step_alg_tflops": round(ALG_GFLOP_PER_IMAGE.get(S, 0) * B / ms, 2)}
+    busy, busy_all, busy_src = pmc_mfma_busy(args.dtype)
+    if busy is not None and (S, B) == (64, 128):
+        # north_star's own wording of the target ("MFMA utilisation ... from rocprof"): matrix-pipe busy cycles over
+        # SIMD cycles, from a separate rocprofv3 PMC pass of this command (offline)
+        roofline["mfma_busy_frac"] = round(busy, 4)
+        roofline["mfma_busy_frac_whole_step"] = round(busy_all, 4)
+        roofline["mfma_busy_source"] = f"{busy_src}: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE pass of bench.py --graph 0, measured offline"
     # the 3-channel image-side layers (<= 20 FLOP/B, priced against HBM): own kernels, own roofline
     roofline_edge = None
     if ed["launches"]:
@@ -391,6 +432,19 @@ def main():
            "roofline": roofline}
     if roofline_edge is not None:
         out["roofline_edge"] = roofline_edge
+    if bn["launches"]:
+        # the second-largest consumer of the step: every launch of csrc/bn_act.hip (BatchNorm finalize, normalise +
+        # activation, backward reduce + apply, activation backward, bias-gradient column sums) against HBM.  Algorithmic
+        # bytes: 2 |Y| per forward pass of a BatchNorm layer, 5 |Y| per backward pass (ops._bn_bytes)
+        gbs = bn["bytes"] / (bn["ms"] * 1e-3) / 1e9
+        out["roofline_bn"] = {"bound": "hbm", "kernel": "bn_act.hip: BatchNorm finalize / normalise + activation / backward reduce + apply, "
+                                                        "activation backward, bias-gradient sums",
+                              "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                              "traffic": None, "launches_per_step": bn["launches"] // args.steps,
+                              "avg_launch_us": round(bn["ms"] * 1e3 / bn["launches"], 2),
+                              "alg_mbytes_per_step": round(bn["bytes"] / args.steps / 1e6, 1),
+                              "us_per_step": round(bn["ms"] * 1e3 / args.steps, 1),
+                              "share_of_step": round(bn["ms"] / args.steps / ms, 3)}
     f8 = fam.get("gather_gemm_fp8", dict(launches=0, ms=0.0, flops=0, bytes=0))
     if f8["launches"]:
         a8 = f8["flops"] / (f8["ms"] * 1e-3) / 1e12
@@ -401,6 +455,7 @@ def main():
                                "share_of_step": round(f8["ms"] / args.steps / ms, 3)}
     if world == 1 and not multi and not args.no_extra_paths:
         del tr, e, g, d, oE, oG, oD
+        out["denoise_path"] = denoise_path(V, S, B, dev, args.dtype, resident)
         out["parity_path"] = parity_path(V, S, B, dev, resident)
         out["elided_path"] = elided_path(V, S, B, dev, args.dtype, resident)
         out["dropin_path"] = dropin_path(V, S, B, dev, args.dtype, resident)

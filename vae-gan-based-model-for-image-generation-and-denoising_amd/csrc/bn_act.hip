@@ -649,10 +649,10 @@ int launch_reduce(const void* x, const void* dy, const float* scale, const float
     VG_CHECK_ARG(partial != nullptr && capacity >= p.nparts * groups, VG_EINVAL);
     dim3 grid(p.nparts * groups, p.ncolblk);
     if (dtype == VG_F32)
-        hipLaunchKernelGGL((col_reduce_kernel<VG_F32, MODE>), grid, dim3(256), 0, s, x, dy, scale, shift, mean, invstd,
+        vg_launch_timed(4, (col_reduce_kernel<VG_F32, MODE>), grid, dim3(256), 0, s, x, dy, scale, shift, mean, invstd,
                            rows, C, act, slope, partial, p.rows_per_part, rpg, p.nparts, gstride);
     else
-        hipLaunchKernelGGL((col_reduce_kernel<VG_BF16, MODE>), grid, dim3(256), 0, s, x, dy, scale, shift, mean, invstd,
+        vg_launch_timed(4, (col_reduce_kernel<VG_BF16, MODE>), grid, dim3(256), 0, s, x, dy, scale, shift, mean, invstd,
                            rows, C, act, slope, partial, p.rows_per_part, rpg, p.nparts, gstride);
     return VG_LAUNCH_RC();
 }
@@ -664,7 +664,7 @@ extern "C" int vg_bn_finalize(const float* stats, int nparts, int C, int64_t cou
                               float* mean, float* invstd, float* scale, float* shift, void* stream) {
     VG_CHECK_ARG(stats && nparts > 0 && C > 0 && count > 0 && mean && invstd && scale && shift, VG_EINVAL);
     VG_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), VG_EINVAL);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_PL), 0, vg_stream(stream), stats, nparts, C,
+    vg_launch_timed(4, bn_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_PL), 0, vg_stream(stream), stats, nparts, C,
                        (double)count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale,
                        shift);
     return VG_LAUNCH_RC();
@@ -676,7 +676,7 @@ extern "C" int vg_bn_finalize_grouped(const float* stats, int nparts_per_group, 
                                       float* coeffs, void* stream) {
     VG_CHECK_ARG(stats && coeffs && nparts_per_group > 0 && groups > 0 && C > 0 && count_per_group > 0, VG_EINVAL);
     VG_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), VG_EINVAL);
-    hipLaunchKernelGGL(bn_finalize_grouped_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_PL), 0,
+    vg_launch_timed(4, bn_finalize_grouped_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_PL), 0,
                        vg_stream(stream), stats, nparts_per_group, groups, C, (double)count_per_group, gamma, beta,
                        running_mean, running_var, momentum, eps, coeffs);
     return VG_LAUNCH_RC();
@@ -688,7 +688,7 @@ extern "C" int vg_bn_backward_finalize_grouped(const float* partial, int nparts_
                                                void* stream) {
     VG_CHECK_ARG(partial && coeffs && coef && nparts_per_group > 0 && groups > 0 && C > 0 && count_per_group > 0,
                  VG_EINVAL);
-    hipLaunchKernelGGL(bn_bwd_finalize_grouped_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_PL), 0,
+    vg_launch_timed(4, bn_bwd_finalize_grouped_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_PL), 0,
                        vg_stream(stream), partial, nparts_per_group, groups, C, (double)count_per_group, gamma, coeffs,
                        dgamma, dbeta, accumulate, coef);
     return VG_LAUNCH_RC();
@@ -696,7 +696,7 @@ extern "C" int vg_bn_backward_finalize_grouped(const float* partial, int nparts_
 
 extern "C" int vg_slab_sums(const float* slabs, int nparts, int C, double* sums, void* stream) {
     VG_CHECK_ARG(slabs && sums && nparts > 0 && C > 0, VG_EINVAL);
-    hipLaunchKernelGGL(slab_sums_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_PL), 0, vg_stream(stream),
+    vg_launch_timed(4, slab_sums_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_PL), 0, vg_stream(stream),
                        slabs, nparts, C, sums);
     return VG_LAUNCH_RC();
 }
@@ -706,7 +706,7 @@ extern "C" int vg_bn_finalize_sums(const double* sums, int C, int64_t count, con
                                    float* invstd, float* scale, float* shift, void* stream) {
     VG_CHECK_ARG(sums && C > 0 && count > 0 && mean && invstd && scale && shift, VG_EINVAL);
     VG_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), VG_EINVAL);
-    hipLaunchKernelGGL(bn_finalize_sums_kernel, dim3((C + 255) / 256), dim3(256), 0, vg_stream(stream), sums, C,
+    vg_launch_timed(4, bn_finalize_sums_kernel, dim3((C + 255) / 256), dim3(256), 0, vg_stream(stream), sums, C,
                        (double)count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale,
                        shift);
     return VG_LAUNCH_RC();
@@ -716,7 +716,7 @@ extern "C" int vg_bn_backward_finalize_sums(const double* global_sums, const dou
                                             const float* gamma, const float* invstd, float* dgamma, float* dbeta,
                                             int accumulate, float* coef, void* stream) {
     VG_CHECK_ARG(global_sums && local_sums && C > 0 && count > 0 && invstd && coef, VG_EINVAL);
-    hipLaunchKernelGGL(bn_bwd_finalize_sums_kernel, dim3((C + 255) / 256), dim3(256), 0, vg_stream(stream),
+    vg_launch_timed(4, bn_bwd_finalize_sums_kernel, dim3((C + 255) / 256), dim3(256), 0, vg_stream(stream),
                        global_sums, local_sums, C, (double)count, gamma, invstd, dgamma, dbeta, accumulate, coef);
     return VG_LAUNCH_RC();
 }
@@ -725,7 +725,7 @@ extern "C" int vg_bn_eval_coeffs(const float* gamma, const float* beta, const fl
                                  const float* running_var, float eps, int C, float* scale, float* shift,
                                  void* stream) {
     VG_CHECK_ARG(running_mean && running_var && scale && shift && C > 0, VG_EINVAL);
-    hipLaunchKernelGGL(bn_eval_kernel, dim3((C + 63) / 64), dim3(64), 0, vg_stream(stream), gamma, beta, running_mean,
+    vg_launch_timed(4, bn_eval_kernel, dim3((C + 63) / 64), dim3(64), 0, vg_stream(stream), gamma, beta, running_mean,
                        running_var, eps, C, scale, shift);
     return VG_LAUNCH_RC();
 }
@@ -750,7 +750,7 @@ extern "C" int vg_bn_finalize_act_forward(const void* x, void* y, const float* s
     int64_t rpb = (rpg + want - 1) / want;
     rpb = (rpb + 127) / 128 * 128;
     const int rb = (int)((rpg + rpb - 1) / rpb);
-    hipLaunchKernelGGL(bn_fin_act_fwd_kernel, dim3(rb, slices, groups), dim3(FF_TH), 0, vg_stream(stream),
+    vg_launch_timed(4, bn_fin_act_fwd_kernel, dim3(rb, slices, groups), dim3(FF_TH), 0, vg_stream(stream),
                        reinterpret_cast<const uint16_t*>(x), reinterpret_cast<uint16_t*>(y), stats, nparts_per_group, groups,
                        C, (double)rpg, gamma, beta, running_mean, running_var, momentum, eps, coeffs, rpg, (int)rpb, act,
                        slope);
@@ -771,7 +771,7 @@ extern "C" int vg_bn_backward_finalize_apply(const void* x, const void* dy, void
     int64_t rpb = (rpg + want - 1) / want;
     rpb = (rpb + 127) / 128 * 128;
     const int rb = (int)((rpg + rpb - 1) / rpb);
-    hipLaunchKernelGGL(bn_bwd_fin_apply_kernel, dim3(rb, slices, groups), dim3(FF_TH), 0, vg_stream(stream),
+    vg_launch_timed(4, bn_bwd_fin_apply_kernel, dim3(rb, slices, groups), dim3(FF_TH), 0, vg_stream(stream),
                        reinterpret_cast<const uint16_t*>(x), reinterpret_cast<const uint16_t*>(dy),
                        reinterpret_cast<uint16_t*>(dx), partial, nparts_per_group, groups, C, (double)rpg, gamma, coeffs,
                        dgamma, dbeta, accumulate, rpg, (int)rpb, act, slope);
@@ -796,10 +796,10 @@ extern "C" int vg_bn_act_forward_fp8(const void* x, void* y, void* y8, const flo
     const int64_t nvec = rows * C / 4;
     const int64_t nvg = nvec / groups;
     if (dtype == VG_F32)
-        hipLaunchKernelGGL(bn_act_fwd_kernel<VG_F32>, dim3(ew_blocks(nvec)), dim3(256), 0, vg_stream(stream), x, y,
+        vg_launch_timed(4, bn_act_fwd_kernel<VG_F32>, dim3(ew_blocks(nvec)), dim3(256), 0, vg_stream(stream), x, y,
                            scale, shift, nvec, C / 4, act, slope, nvg, gstride, (uint32_t*)nullptr);
     else
-        hipLaunchKernelGGL(bn_act_fwd_kernel<VG_BF16>, dim3(ew_blocks(nvec)), dim3(256), 0, vg_stream(stream), x, y,
+        vg_launch_timed(4, bn_act_fwd_kernel<VG_BF16>, dim3(ew_blocks(nvec)), dim3(256), 0, vg_stream(stream), x, y,
                            scale, shift, nvec, C / 4, act, slope, nvg, gstride, reinterpret_cast<uint32_t*>(y8));
     return VG_LAUNCH_RC();
 }
@@ -827,7 +827,7 @@ extern "C" int vg_bn_backward_finalize(const float* partial, int nparts, int C, 
                                        const float* invstd, float* dgamma, float* dbeta, int accumulate, float* coef,
                                        void* stream) {
     VG_CHECK_ARG(partial && nparts > 0 && C > 0 && count > 0 && invstd && coef, VG_EINVAL);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_PL), 0, vg_stream(stream), partial, nparts, C,
+    vg_launch_timed(4, bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_PL), 0, vg_stream(stream), partial, nparts, C,
                        (double)count, gamma, invstd, dgamma, dbeta, accumulate, coef);
     return VG_LAUNCH_RC();
 }
@@ -843,10 +843,10 @@ extern "C" int vg_bn_act_backward_apply(const void* x, const void* dy, void* dx,
     const int64_t nvec = rows * C / 4;
     const int64_t nvg = nvec / groups;
     if (dtype == VG_F32)
-        hipLaunchKernelGGL(bn_act_bwd_apply_kernel<VG_F32>, dim3(ew_blocks(nvec)), dim3(256), 0, vg_stream(stream), x,
+        vg_launch_timed(4, bn_act_bwd_apply_kernel<VG_F32>, dim3(ew_blocks(nvec)), dim3(256), 0, vg_stream(stream), x,
                            dy, dx, scale, shift, mean, invstd, coef, nvec, C / 4, C, act, slope, nvg, gstride, cstride);
     else
-        hipLaunchKernelGGL(bn_act_bwd_apply_kernel<VG_BF16>, dim3(ew_blocks(nvec)), dim3(256), 0, vg_stream(stream), x,
+        vg_launch_timed(4, bn_act_bwd_apply_kernel<VG_BF16>, dim3(ew_blocks(nvec)), dim3(256), 0, vg_stream(stream), x,
                            dy, dx, scale, shift, mean, invstd, coef, nvec, C / 4, C, act, slope, nvg, gstride, cstride);
     return VG_LAUNCH_RC();
 }
@@ -857,10 +857,10 @@ extern "C" int vg_act_backward(const void* x, const void* dy, void* dx, int64_t 
     VG_CHECK_ARG(dtype == VG_F32 || dtype == VG_BF16, VG_ENOSUP);
     const int64_t nvec = n / 4;
     if (dtype == VG_F32)
-        hipLaunchKernelGGL(act_bwd_kernel<VG_F32>, dim3(ew_blocks(nvec)), dim3(256), 0, vg_stream(stream), x, dy, dx,
+        vg_launch_timed(4, act_bwd_kernel<VG_F32>, dim3(ew_blocks(nvec)), dim3(256), 0, vg_stream(stream), x, dy, dx,
                            nvec, act, slope);
     else
-        hipLaunchKernelGGL(act_bwd_kernel<VG_BF16>, dim3(ew_blocks(nvec)), dim3(256), 0, vg_stream(stream), x, dy, dx,
+        vg_launch_timed(4, act_bwd_kernel<VG_BF16>, dim3(ew_blocks(nvec)), dim3(256), 0, vg_stream(stream), x, dy, dx,
                            nvec, act, slope);
     return VG_LAUNCH_RC();
 }
@@ -874,7 +874,7 @@ extern "C" int vg_bias_grad(const void* dy, int64_t rows, int C, int NC, float* 
     rc = launch_reduce<0>(dy, nullptr, nullptr, nullptr, nullptr, nullptr, rows, C, 0, 0.f, ws, ws_capacity, &nparts,
                           dtype, vg_stream(stream));
     if (rc) return rc;
-    hipLaunchKernelGGL(bias_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_PL), 0, vg_stream(stream), ws, nparts, C, NC,
+    vg_launch_timed(4, bias_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_PL), 0, vg_stream(stream), ws, nparts, C, NC,
                        dbias, accumulate);
     return VG_LAUNCH_RC();
 }

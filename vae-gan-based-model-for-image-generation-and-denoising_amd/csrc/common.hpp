@@ -110,7 +110,7 @@ struct VgTiming {
     bool on = false;
     std::mutex mu;
     std::vector<hipEvent_t> pool;                                 // free events
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> rec[4];         // family 0: gather-GEMM, 1: wgrad, 2: edge layers (HBM-bound), 3: fp8 gather-GEMM
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> rec[5];         // family 0: gather-GEMM, 1: wgrad, 2: edge layers (HBM-bound), 3: fp8 gather-GEMM, 4: BatchNorm / activation / bias-gradient passes (bn_act.hip, HBM-bound)
 };
 VgTiming& vg_timing();
 

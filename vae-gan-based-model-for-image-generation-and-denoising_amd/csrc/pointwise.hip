@@ -855,7 +855,7 @@ extern "C" int vg_timing_enable(int on) {
 
 // Synchronises the recorded events of `family`, returns the summed kernel time and the launch count, recycles them.
 extern "C" int vg_timing_collect(int family, double* total_ms, int* launches) {
-    VG_CHECK_ARG(family >= 0 && family < 4 && total_ms && launches, VG_EINVAL);
+    VG_CHECK_ARG(family >= 0 && family < 5 && total_ms && launches, VG_EINVAL);
     VgTiming& t = vg_timing();
     std::lock_guard<std::mutex> g(t.mu);
     double sum = 0.0;

@@ -60,7 +60,9 @@ class KernelTimer:
     """Live timing of the GEMM-class launches (bench.py's roofline leg): the library brackets each kernel with a
     HIP start/stop event pair on its launch stream (vg_timing_*); this object only adds up the algorithmic
     FLOP / bytes of the same launches.  Off by default."""
-    FAMILIES = {"gather_gemm": 0, "wgrad": 1, "edge": 2, "gather_gemm_fp8": 3}
+    # "bn": every launch of csrc/bn_act.hip -- BatchNorm finalize / normalise + activation / backward reduce + apply,
+    # plain activation backward, bias-gradient column sums: HBM-bound passes over the activation tensors
+    FAMILIES = {"gather_gemm": 0, "wgrad": 1, "edge": 2, "gather_gemm_fp8": 3, "bn": 4}
 
     def __init__(self):
         self.acc = {k: dict(flops=0, bytes=0) for k in self.FAMILIES}
@@ -88,6 +90,14 @@ class KernelTimer:
 
 
 TIMER = None
+
+
+def _bn_bytes(passes: int, numel: int, dtype: int) -> None:
+    """Algorithmic HBM bytes of a BatchNorm / activation pass for bench.py's roofline_bn: `passes` tensor-sized streams
+    (forward: read the raw output, write the activated one = 2; backward: reduce reads x and dy, apply reads x and dy and
+    writes dx = 5; the small statistics / coefficient vectors are not counted)."""
+    if TIMER is not None:
+        TIMER.begin("bn", 0, passes * numel * (4 if dtype == F32 else 2))
 
 # ---- binding ---------------------------------------------------------------------------------------------------------
 # The kernels live behind the C ABI (include/vaegan_hip.h).  Two faces reach it from Python:
@@ -474,6 +484,7 @@ def bn_act_forward(x, coeffs, rows, C, act, slope, dtype, out=None, want_fp8=Fal
     _need_cuda(x, coeffs)
     y = out if out is not None else torch.empty_like(x)
     groups = coeffs.shape[0] if coeffs is not None else 1
+    _bn_bytes(2, x.numel(), dtype)
     if want_fp8:
         y8 = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
         L.check(L.load().vg_bn_act_forward_fp8(x.data_ptr(), y.data_ptr(), y8.data_ptr(),
@@ -503,6 +514,7 @@ def bn_finalize_act_forward(x, stats, nparts, C, rows, gamma, beta, running_mean
     _need_cuda(x, stats)
     co = torch.empty(groups, 4, C, dtype=torch.float32, device=x.device)
     y = torch.empty_like(x)
+    _bn_bytes(2, x.numel(), dtype)
     L.check(lib.vg_bn_finalize_act_forward(x.data_ptr(), y.data_ptr(), stats.data_ptr(), nparts // groups, groups, C, rows,
                                            L.ptr(gamma), L.ptr(beta), L.ptr(running_mean), L.ptr(running_var), momentum, eps,
                                            co.data_ptr(), act, slope, dtype, L.stream_ptr()), "vg_bn_finalize_act_forward")
@@ -513,6 +525,7 @@ def channel_stats(x, rows, C, dtype):
     n = c_int(0)
     cap = 1024
     stats = WS.get("stats", cap * 2 * C * 4, x.device)
+    _bn_bytes(1, x.numel(), dtype)
     L.check(L.load().vg_channel_stats(x.data_ptr(), rows, C, stats.data_ptr(), cap, byref(n), dtype, L.stream_ptr()),
             "vg_channel_stats")
     return stats, n.value
@@ -525,6 +538,7 @@ def bn_act_backward(x, dy, coeffs, rows, C, count, gamma, act, slope, dgamma, db
     groups = coeffs.shape[0]
     n = c_int(0)
     cap = 2048
+    _bn_bytes(5, x.numel(), dtype)
     partial = WS.get("bnbwd", cap * 2 * C * 4, x.device)
     L.check(lib.vg_bn_act_backward_reduce(x.data_ptr(), dy.data_ptr(), coeffs[0, 2].data_ptr(),
                                           coeffs[0, 3].data_ptr(), coeffs[0, 0].data_ptr(), coeffs[0, 1].data_ptr(),
@@ -568,6 +582,7 @@ def bn_act_backward(x, dy, coeffs, rows, C, count, gamma, act, slope, dgamma, db
 
 def act_backward(x, dy, act, slope, dtype):
     dx = torch.empty_like(x)
+    _bn_bytes(3, x.numel(), dtype)
     L.check(L.load().vg_act_backward(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.numel(), act, slope, dtype,
                                      L.stream_ptr()), "vg_act_backward")
     return dx
@@ -575,6 +590,7 @@ def act_backward(x, dy, act, slope, dtype):
 
 def bias_grad(dy, rows, C, NC, dbias, accumulate, dtype):
     cap = 1024
+    _bn_bytes(1, rows * C, dtype)
     ws = WS.get("biasgrad", cap * 2 * C * 4, dy.device)
     L.check(L.load().vg_bias_grad(dy.data_ptr(), rows, C, NC, dbias.data_ptr(), 1 if accumulate else 0,
                                   ws.data_ptr(), cap, dtype, L.stream_ptr()), "vg_bias_grad")
