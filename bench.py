@@ -190,7 +190,7 @@ def denoise_path(V, S, B, dev, dtype, inputs, steps=20):
             "mode": "denoise_eval (eval-mode E -> reparam -> G, MSE, KL, PSNR, SSIM; eager launches, 2 host reads per batch)"}
 
 
-def dropin_path(V, S, B, dev, dtype, inputs, steps=10):
+def dropin_path(V, S, B, dev, dtype, inputs, steps=10, graph=True):
     """the reference trainer's own code shape (vaegan_code.py:65-135 -- module calls, torch
     ops between them, nn.BCELoss / nn.MSELoss, .backward(), optimizer.step()) on the engine's nn.Modules + Adam:
     autograd drives the HIP kernel chains, every launch marshalled through ctypes, NCHW<->NHWC at every module edge."""
@@ -231,9 +231,17 @@ def dropin_path(V, S, B, dev, dtype, inputs, steps=10):
         return total
 
     dt = time_steps(step, 3, steps)
-    return {"dtype": {"fp32": "f32", "bf16": "bf16"}[dtype], "value": round(B / dt, 1), "unit": "images/sec",
-            "ms_per_step": round(dt * 1e3, 3), "steps": steps,
-            "mode": "reference loop on vaegan_amd nn.Modules + Adam (autograd, eager)", "binding": ops_binding()}
+    out = {"dtype": {"fp32": "f32", "bf16": "bf16"}[dtype], "value": round(B / dt, 1), "unit": "images/sec",
+           "ms_per_step": round(dt * 1e3, 3), "steps": steps,
+           "mode": "reference loop on vaegan_amd nn.Modules + Adam (autograd, eager)", "binding": ops_binding()}
+    if graph:
+        # the same function behind vaegan_amd.graphed(): captured once (forward, autograd backward, zero_grad / step, the
+        # randn_like draws), then replayed -- INTEGRATION.md section 1's fourth line
+        gstep = V.graphed(step, modules=(encoder, decoder, discriminator), optimizers=(opt_E, opt_Dec, opt_Dis))
+        dtg = time_steps(gstep, 4, 2 * steps)
+        out["graphed"] = {"value": round(B / dtg, 1), "ms_per_step": round(dtg * 1e3, 3), "steps": 2 * steps,
+                          "mode": "the same step function wrapped in vaegan_amd.graphed(...): hipGraph replay"}
+    return out
 
 
 def main():
@@ -461,7 +469,7 @@ def main():
         out["dropin_path"] = dropin_path(V, S, B, dev, args.dtype, resident)
         try:                                    # the same loop with the hot ops bound through torch.ops.vaegan.*
             ops.set_binding("torchops")
-            alt = dropin_path(V, S, B, dev, args.dtype, resident)
+            alt = dropin_path(V, S, B, dev, args.dtype, resident, graph=False)
             out["dropin_path"]["torchops_binding"] = {"value": alt["value"], "ms_per_step": alt["ms_per_step"]}
         except RuntimeError as ex:
             out["dropin_path"]["torchops_binding"] = {"error": str(ex)[:200]}

@@ -737,6 +737,83 @@ def test_dropin_autograd_path_matches_direct_trainer_and_oracle():
             assert rel(v, ref[n]) <= tol, f"step {step} {n}: drop-in {v} oracle {ref[n]}"
 
 
+def _reference_shaped_step(encoder, decoder, discriminator, opt_E, opt_Dec, opt_Dis, bce, mse):
+    """vaegan_code.py:65-135 as a function of (real_images, eps_z, eps_real, eps_recon; epoch) returning device tensors."""
+    def step(real_images, ez, er, ec, epoch=60):
+        B = real_images.size(0)
+        mu, logvar = encoder(real_images)
+        logvar = torch.clamp(logvar, min=-10, max=10)
+        std = torch.exp(0.5 * logvar)
+        z = (mu + std * ez).unsqueeze(-1).unsqueeze(-1)
+        recon_images = decoder(z)
+        real_labels = torch.full((B,), 0.9, device=DEV)
+        fake_labels = torch.full((B,), 0.1, device=DEV)
+        real_images_noisy = real_images + 0.05 * er
+        recon_images_noisy = recon_images + 0.05 * ec
+        dl = []
+        for _ in range(2):
+            d_loss = bce(discriminator(real_images_noisy), real_labels) + bce(discriminator(recon_images_noisy.detach()), fake_labels)
+            opt_Dis.zero_grad()
+            d_loss.backward()
+            opt_Dis.step()
+            dl.append(d_loss.detach())
+        fake_output = discriminator(recon_images_noisy)
+        recon_loss = mse(recon_images, real_images)
+        kl_loss = -0.5 * torch.sum(1 + logvar - mu.pow(2) - logvar.exp()) / B
+        g_loss_adv = bce(fake_output, real_labels)
+        total = recon_loss + 0.1 * min(1.0, epoch / 50) * kl_loss + 0.1 * g_loss_adv
+        opt_E.zero_grad()
+        opt_Dec.zero_grad()
+        total.backward()
+        opt_E.step()
+        opt_Dec.step()
+        return torch.stack([recon_loss.detach(), kl_loss.detach(), g_loss_adv.detach(), dl[0], dl[1]])
+    return step
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_graphed_reference_shaped_step_equals_the_eager_one_and_the_oracle(dtype):
+    """vaegan_amd.graphed(step): the reference's loop body (module calls, torch ops, nn.BCELoss / nn.MSELoss, .backward(),
+    optimizer.step()) captured into ONE hipGraph -- autograd's backward included -- and replayed: bit-identical to the
+    same function called eagerly (losses of 5 iterations, parameters, BatchNorm buffers, Adam state, host-side step /
+    num_batches_tracked mirrors), first-iteration losses against the oracle (fp32: FIRST_STEP_TOL; bf16: 3e-2), a new
+    keyword scalar (epoch -> KL weight) re-captures."""
+    S, B = 64, 8
+    res = []
+    for use_graph in (False, True):
+        V.configure_seed(42)
+        nets = (V.Encoder([3, S, S], 100, dtype=dtype), V.Generator(nz=100, img_size=S, dtype=dtype),
+                V.Discriminator(img_size=S, dtype=dtype))
+        nets[1].apply(V.weights_init), nets[2].apply(V.weights_init)
+        for m in nets:
+            m.to(DEV), m.train()
+        opts = tuple(V.Adam(m.parameters(), lr=2e-4) for m in nets)
+        step = _reference_shaped_step(*nets, *opts, torch.nn.BCELoss(), torch.nn.MSELoss(reduction="mean"))
+        if use_graph:
+            step = V.graphed(step, modules=nets, optimizers=opts)
+        losses = []
+        for i in range(5):
+            ins = [t.to(DEV) for t in make_inputs(B, S, 7300 + i)]
+            losses.append(step(*ins, epoch=60).clone())
+        losses.append(step(*[t.to(DEV) for t in make_inputs(B, S, 7306)], epoch=25).clone())     # other KL weight
+        if use_graph:
+            assert len(step._graphs) == 1 and sum(step._seen.values()) == 2 + 1     # epoch=25: still in its eager warm-up
+        torch.cuda.synchronize()
+        res.append((torch.stack(losses).cpu(), [{k: v.cpu() for k, v in m.state_dict().items()} for m in nets],
+                    [(o.exp_avg.cpu(), o.exp_avg_sq.cpu(), o.steps, float(o.state_dev[0])) for o in opts]))
+    assert torch.equal(res[0][0], res[1][0])
+    for sa, sb in zip(res[0][1], res[1][1]):
+        for k in sa:
+            assert torch.equal(sa[k], sb[k]), k
+    for a, b in zip(res[0][2], res[1][2]):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2:] == b[2:]
+    assert res[1][2][2][2] == 12 and res[1][2][0][2] == 6          # D stepped twice per iteration, E once
+    ref = R.RefVAEGAN(img_size=S, seed=42).train_step(*make_inputs(B, S, 7300), 60)
+    for j, n in enumerate(V.LOSS_NAMES):
+        tol = FIRST_STEP_TOL[n] if dtype == "fp32" else 3e-2
+        assert rel(float(res[1][0][0, j]), ref[n]) <= tol, f"graphed drop-in {dtype} {n}: {float(res[1][0][0, j])} oracle {ref[n]}"
+
+
 def test_modules_losses_mirror_torch():
     p = torch.rand(7, device=DEV) * 0.98 + 0.01
     t = torch.full((7,), 0.9, device=DEV)

@@ -4,12 +4,14 @@ module at the repository root (this directory's name is not a Python identifier)
 Drop-in surface (INTEGRATION.md): ``Encoder``, ``ConvBlock`` (main_vae.py:20-58), ``Generator``,
 ``Discriminator``, ``weights_init`` (gan_code.py:16-97), ``Adam`` (torch.optim.Adam as used at
 vaegan_code.py:42-44), ``BCELoss`` / ``MSELoss`` (vaegan_code.py:46-47), ``configure_seed``
-(utils.py:6-14) and ``VAEGANTrainer`` (the loop body of vaegan_code.py:65-135).
+(utils.py:6-14), ``VAEGANTrainer`` (the loop body of vaegan_code.py:65-135) and ``graphed`` (hipGraph replay of a
+reference-shaped step function).
 """
 from . import data  # noqa: F401
 from . import geometry  # noqa: F401
 from .ddp import GradReducer
 from .denoise import denoise_eval, validation_epoch
+from .graphed import graphed
 from .losses import BCELoss, MSELoss
 from .nets import ConvBlock, Discriminator, Encoder, Generator, weights_init
 from .optim import Adam
@@ -18,4 +20,4 @@ from .trainer import LOSS_NAMES, VAEGANTrainer
 from .utils import configure_seed
 
 __all__ = ["ConvBlock", "Encoder", "Generator", "Discriminator", "weights_init", "Adam", "BCELoss", "MSELoss",
-           "VAEGANTrainer", "LOSS_NAMES", "configure_seed", "geometry", "denoise_eval", "validation_epoch", "GradReducer", "data", "VAETrainer", "DCGANTrainer", "WGANTrainer"]
+           "VAEGANTrainer", "LOSS_NAMES", "configure_seed", "geometry", "denoise_eval", "validation_epoch", "GradReducer", "data", "VAETrainer", "DCGANTrainer", "WGANTrainer", "graphed"]

@@ -31,6 +31,9 @@ _FP8_NAMES = ("fp8", "float8", "e4m3")
 
 
 
+DIRECT_PARAM_GRADS = True     # see _StackFn.backward
+
+
 def _is_fp8(dtype) -> bool:
     return isinstance(dtype, str) and dtype in _FP8_NAMES
 
@@ -114,10 +117,15 @@ class _StackFn(torch.autograd.Function):
         net = ctx.net
         if ctx.saved is None:
             raise RuntimeError("backward called on a forward that ran under torch.no_grad()")
-        sink = GradSink(direct=False)
-        dx = net._backward_impl(ctx.saved, douts, ctx.needs_input_grad[1], sink,
-                                param_grads=any(ctx.needs_input_grad[2:]))
-        grads = [sink.out.get(id(p)) for p in net._engine.params()]
+        # Parameter gradients.  Default (DIRECT_PARAM_GRADS): the kernels write / accumulate straight into param.grad
+        # -- the optimizer's flat gradient buffer (optim.Adam), overwrite-after-zero_grad as in the direct trainer --
+        # and autograd is handed None for the parameters: no AccumulateGrad add kernel per parameter (91 small ATen
+        # launches per reference-shaped iteration).  torch.autograd.grad(...) callers, who want the gradients RETURNED,
+        # set nets.DIRECT_PARAM_GRADS = False.
+        need_p = any(ctx.needs_input_grad[2:])
+        sink = GradSink(direct=DIRECT_PARAM_GRADS)
+        dx = net._backward_impl(ctx.saved, douts, ctx.needs_input_grad[1], sink, param_grads=need_p)
+        grads = [None if DIRECT_PARAM_GRADS else sink.out.get(id(p)) for p in net._engine.params()]
         ctx.saved = None
         return (None, dx, *grads)
 
