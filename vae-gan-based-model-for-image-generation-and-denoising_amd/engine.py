@@ -541,4 +541,19 @@ class StackEngine:
             ops.wgrad(wg, c["x"], dY, gw, acc, dt, alg=st.alg(B, dt))
         if st.has_bias:
             gb, accb = sink.get(st.conv.bias)
-            ops.bias_grad(dY, rows, OC, st.cout, gb, accb, dt)
+            if st.bn is not None:
+                # A conv bias directly in front of a train-mode BatchNorm (main_vae.py:23-24): the batch mean removes it,
+                # so its gradient -- the column sums of the BatchNorm backward's output -- is IDENTICALLY ZERO in exact
+                # arithmetic (sum_m dx = a*sum(dz) - N*a*mean(dz) - b*sum(xhat) = 0).  What the reference's autograd
+                # returns there is the fp32 rounding residue of that expression (|g| ~ 1e-8, a different residue in every
+                # implementation; tests/test_gpu_parity.py skips these tensors for that reason).  The engine writes the
+                # exact value, 0: no column-reduce + finalize launches (8 per iteration at S=64).  The slot is zeroed once
+                # and left alone while nothing else has written it.
+                if not accb and getattr(st.conv.bias, "_vg_zero_slot", None) != gb.data_ptr():
+                    ops.memset_zero(gb)
+                    # (remembered only for a slot of optim.Adam's flat gradient buffer, which nothing else writes; any
+                    # other gradient tensor may be a recycled allocation and is zeroed every time)
+                    homed = sink.direct and getattr(st.conv.bias, "_vg_homed", None) == gb.data_ptr()
+                    st.conv.bias._vg_zero_slot = gb.data_ptr() if homed else None
+            else:
+                ops.bias_grad(dY, rows, OC, st.cout, gb, accb, dt)

@@ -80,6 +80,7 @@ class Adam:
                 p.data = self.flat_p[o:o + p.numel()].view(p.shape)
                 p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
                 p._vg_fresh = True
+                p._vg_homed = p.grad.data_ptr()            # address of this parameter's slot in the flat gradient buffer
         self.grad_scale = 1.0                                   # 1/world_size under data parallelism
         self.steps = 0
         bump_weights_epoch(self.params)
