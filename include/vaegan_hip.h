@@ -51,7 +51,7 @@ extern "C" {
 #define VG_ABI_VERSION 8   /* 2: vg_pack_desc.tile_start, SyncBN / WGAN / data-path entry points; 3: in-kernel noise (vg_*_rng);
                              4: vg_bn_finalize_act_forward, vg_bn_backward_finalize_apply;
                              7: vg_bce_pair_forward_backward;
-                             8: round-3 prune -- the opt-in experiments of ABI 5 / 6 that measured slower (input prologue of
+                             8: vg_head_backward; round-3 prune -- the opt-in experiments of ABI 5 / 6 that measured slower (input prologue of
                                 vg_tn_desc / vg_ew_desc, vg_gg_desc.bnb_*) are gone from the descriptors; vg_reload_switches */
 int vg_abi_version(void);
 /* The library reads its optional kernel-selection switches (VG_* environment variables, DESIGN.md "Runtime switches")
@@ -375,6 +375,15 @@ int vg_bce_forward_backward(const float* p, float target, int B, float gscale,
  * calls, the second accumulating. */
 int vg_bce_pair_forward_backward(const float* p, float target0, float target1, int B, float gscale,
                                  float* loss, int accumulate, float* dp, void* stream);
+/* Backward of BCE(sigmoid(head)) in ONE launch (round 3; vaegan_code.py:99-104 and :115,133 behind the Discriminator's last
+ * Conv2d, gan_code.py:84-85): for p = [B rows with target0 | B rows with target1] (groups = 2) or B rows with target0
+ * (groups = 1):  loss[0] (+)= sum of the groups' BCE means;  dlogit[r] = gscale * (p - t) / max(p (1 - p), 1e-12) / B * p (1 - p);
+ * dx[r,k] = dlogit[r] * w[k] (dx NULL: skipped);  dw[k] (+)= sum_r dlogit[r] * x[r,k] in the reference layout (dw NULL:
+ * skipped);  dlogit optional output.  Bit-identical to vg_bce[_pair]_forward_backward + vg_dot_sigmoid_backward +
+ * vg_dot_wgrad (same arithmetic, lane mappings and summation orders).  B * groups <= 4096, K % 4 == 0. */
+int vg_head_backward(const float* p, const void* x, const void* w, void* dx, float* dw, float* dlogit, int B, int groups,
+                     float target0, float target1, float gscale, float* loss, int accumulate_loss, int accumulate_dw,
+                     int K, int C, int HW, int dtype, void* stream);
 /* Sibling loop train_wgan (gan_code.py:306-315, :328): loss[0] (+)= sign*mean_b p[b]; dp[b] = sign*gscale/B. */
 int vg_mean_forward_backward(const float* p, float sign, int B, float gscale,
                              float* loss, int accumulate, float* dp, void* stream);

@@ -484,6 +484,27 @@ def test_grouped_discriminator_pass_equals_separate_passes():
         assert float((a - b).abs().max() / b.abs().max()) < 2e-3
 
 
+@pytest.mark.parametrize("dtype,B", [("fp32", 8), ("bf16", 128)])
+def test_fused_head_backward_is_bit_identical_to_the_three_launches(dtype, B):
+    """vg_head_backward (BCE of the Discriminator's output + its gradient + sigmoid backward + the head's data and weight
+    gradients in ONE launch, vaegan_code.py:99-104 / :115,133) against the path it replaces (vg_bce[_pair]_forward_backward,
+    vg_dot_sigmoid_backward, vg_dot_wgrad): two whole iterations, every loss, parameter and Adam moment bit for bit."""
+    outs = []
+    for fused in (True, False):
+        e, g, d, tr = build(64, dtype=dtype)
+        tr.fuse_head_backward = fused
+        ls = []
+        for step in range(2):
+            real, ez, er, ec = (t.to(DEV) for t in make_inputs(B, 64, 4400 + step))
+            ls.append(tr.train_step(real, 60, ez, er, ec)[:5].clone())
+        torch.cuda.synchronize()
+        outs.append((torch.stack(ls).cpu(), [o.flat_p.cpu().clone() for o in (tr.opt_E, tr.opt_G, tr.opt_D)],
+                     [o.exp_avg.cpu().clone() for o in (tr.opt_E, tr.opt_G, tr.opt_D)], tr.opt_D.flat_g.cpu().clone()))
+    assert torch.equal(outs[0][0], outs[1][0])
+    for a, b in zip(outs[0][1] + outs[0][2] + [outs[0][3]], outs[1][1] + outs[1][2] + [outs[1][3]]):
+        assert torch.equal(a, b)
+
+
 class _LocalReducer:
     """world_size-1 stand-in with the whole-buffer GradReducer surface: lets the single GPU exercise the SEGMENTED
     graph path (collectives between hipGraph segments) and records how the trainer drives it."""

@@ -129,6 +129,7 @@ SIGNATURES = {
     "vg_dot_wgrad": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "vg_bce_forward_backward": (c_int, [_P, _F, _I, _F, _P, _I, _P, _P]),
     "vg_bce_pair_forward_backward": (c_int, [_P, _F, _F, _I, _F, _P, _I, _P, _P]),
+    "vg_head_backward": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _F, _P, _I, _I, _I, _I, _I, _I, _P]),
     "vg_mean_forward_backward": (c_int, [_P, _F, _I, _F, _P, _I, _P, _P]),
     "vg_clamp": (c_int, [_P, _L, _F, _F, _P]),
     "vg_mse_forward_backward": (c_int, [_P, _P, _L, _F, _P, _P, _P, _I, _P]),

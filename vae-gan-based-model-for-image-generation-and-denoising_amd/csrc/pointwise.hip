@@ -369,6 +369,106 @@ __global__ __launch_bounds__(1024) void dot_wgrad_kernel(const void* __restrict_
     *dst = accumulate ? (*dst + s) : s;
 }
 
+// One sample's BCE term, -(t * max(log p, -100) + (1 - t) * max(log(1 - p), -100)) (torch.nn.BCELoss),
+// with floating-point contraction OFF: the three kernels that evaluate it (bce_kernel, bce_pair_kernel, head_bwd_kernel)
+// must round identically, and hipcc is free to contract a*b + c*d into an fma around EITHER product.
+__device__ __forceinline__ float bce_term(float pv, float target) {
+#pragma clang fp contract(off)
+    const float l1 = fmaxf(logf(pv), -100.f);
+    const float l2 = fmaxf(logf(1.f - pv), -100.f);
+    const float a = target * l1;
+    const float b = (1.f - target) * l2;
+    return -(a + b);
+}
+
+// ---- Discriminator head, backward of BCE(sigmoid(dot)) in ONE launch (round 3) --------------------------------------
+// What vaegan_code.py:99-104 / :115,133 run behind the head: bce (loss + dL/dp), sigmoid backward, the head's data
+// gradient dx[b,k] = dlogit[b] * w[k] and its weight gradient dw[k] = sum_b dlogit[b] * x[b,k] were three launches
+// (bce[_pair]_kernel, dot_sigmoid_bwd_kernel, dot_wgrad_kernel).  Here a workgroup owns 64 columns k for ALL rows: it
+// re-derives dlogit[0..groups*B) into LDS (B*groups floats; the arithmetic of the three kernels, operation for operation),
+// forms its dw columns with dot_wgrad_kernel's lane mapping and summation order and writes its dx columns; workgroup 0
+// also writes the loss with bce_pair_kernel's mapping -- every output is bit-identical to the three-launch path.
+constexpr int HB_MAXROWS = 4096;
+template <int DT>
+__global__ __launch_bounds__(1024) void head_bwd_kernel(const float* __restrict__ p, const void* __restrict__ x,
+                                                        const void* __restrict__ w, void* __restrict__ dx,
+                                                        float* __restrict__ dw, float* __restrict__ dlogit_out, int B,
+                                                        int groups, float t0, float t1, float gscale,
+                                                        float* __restrict__ loss, int accumulate_loss, int accumulate_dw,
+                                                        int K, int C, int HW) {
+    __shared__ float dl[HB_MAXROWS];
+    __shared__ float red[16][64];
+    __shared__ double lred[2][4];
+    const int R = B * groups;
+    for (int r = threadIdx.x; r < R; r += 1024) {
+        const float target = r < B ? t0 : t1;
+        const float pv = p[r];
+        const float dpv = gscale * ((pv - target) / fmaxf((1.f - pv) * pv, 1e-12f)) / (float)B;     // bce_kernel
+        const float d = dpv * (pv * (1.f - pv));                                                     // dot_sigmoid_bwd_kernel
+        dl[r] = d;
+        if (blockIdx.x == 0 && dlogit_out) dlogit_out[r] = d;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 256) {             // the loss: bce_pair_kernel's 256-thread mapping per half
+        for (int h = 0; h < groups; ++h) {
+            const float target = h == 0 ? t0 : t1;
+            double sacc = 0.0;
+            for (int b = threadIdx.x; b < B; b += 256) {
+                sacc += (double)bce_term(p[h * B + b], target);
+            }
+            sacc = wave_sum_d(sacc);
+            if ((threadIdx.x & 63) == 0) lred[h][threadIdx.x >> 6] = sacc;
+        }
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const float v0 = (float)((lred[0][0] + lred[0][1] + lred[0][2] + lred[0][3]) / (double)B);
+        float out = accumulate_loss ? loss[0] + v0 : v0;
+        if (groups == 2) out = out + (float)((lred[1][0] + lred[1][1] + lred[1][2] + lred[1][3]) / (double)B);
+        loss[0] = out;
+    }
+    // ---- dw: 64 columns x 16 batch lanes, four loads in flight, fixed-order combine (dot_wgrad_kernel) ----
+    const int kl = threadIdx.x & 63, bl = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + kl;
+    if (dw != nullptr) {
+        float s = 0.f;
+        if (k < K) {
+            int b = bl;
+            for (; b + 48 < R; b += 64) {
+                float v[4], g[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { v[u] = load1<DT>(x, (int64_t)(b + 16 * u) * K + k); g[u] = dl[b + 16 * u]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) s += g[u] * v[u];
+            }
+            for (; b < R; b += 16) s += dl[b] * load1<DT>(x, (int64_t)b * K + k);
+        }
+        red[bl][kl] = s;
+        __syncthreads();
+        if (bl == 0 && k < K) {
+            s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += red[r][kl];
+            const int hw = k / C, c = k - hw * C;
+            float* dst = dw + (int64_t)c * HW + hw;               // reference layout [1][C][kh][kw]
+            *dst = accumulate_dw ? (*dst + s) : s;
+        }
+    }
+    // ---- dx: this workgroup's 64 columns of every row, 4 columns (one 8 / 16-byte store) per thread ----
+    if (dx != nullptr) {
+        const int kq = threadIdx.x & 15, bq = threadIdx.x >> 4;
+        const int k4 = blockIdx.x * 64 + kq * 4;
+        if (k4 < K) {
+            const float4 wv = load4<DT>(w, k4);
+            for (int b = bq; b < R; b += 64) {
+                const float d = dl[b];
+                float4 o = wv;
+                o.x *= d; o.y *= d; o.z *= d; o.w *= d;
+                store4<DT>(dx, (int64_t)b * K + k4, o);
+            }
+        }
+    }
+}
+
 // ---- losses -------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void bce_kernel(const float* __restrict__ p, float target, int B, float gscale,
                                                   float* __restrict__ loss, int accumulate, float* __restrict__ dp) {
@@ -376,9 +476,7 @@ __global__ __launch_bounds__(256) void bce_kernel(const float* __restrict__ p, f
     double s = 0.0;
     for (int b = threadIdx.x; b < B; b += blockDim.x) {
         const float pv = p[b];
-        const float l1 = fmaxf(logf(pv), -100.f);
-        const float l2 = fmaxf(logf(1.f - pv), -100.f);
-        s += (double)(-(target * l1 + (1.f - target) * l2));
+        s += (double)bce_term(pv, target);
         if (dp) dp[b] = gscale * ((pv - target) / fmaxf((1.f - pv) * pv, 1e-12f)) / (float)B;
     }
     s = wave_sum_d(s);
@@ -403,9 +501,7 @@ __global__ __launch_bounds__(256) void bce_pair_kernel(const float* __restrict__
         double s = 0.0;
         for (int b = threadIdx.x; b < B; b += blockDim.x) {
             const float pv = p[h * B + b];
-            const float l1 = fmaxf(logf(pv), -100.f);
-            const float l2 = fmaxf(logf(1.f - pv), -100.f);
-            s += (double)(-(target * l1 + (1.f - target) * l2));
+            s += (double)bce_term(pv, target);
             if (dp) dp[h * B + b] = gscale * ((pv - target) / fmaxf((1.f - pv) * pv, 1e-12f)) / (float)B;
         }
         s = wave_sum_d(s);
@@ -757,6 +853,18 @@ extern "C" int vg_bce_pair_forward_backward(const float* p, float target0, float
     VG_CHECK_ARG(p && loss && B > 0, VG_EINVAL);
     hipLaunchKernelGGL(bce_pair_kernel, dim3(1), dim3(256), 0, vg_stream(stream), p, target0, target1, B, gscale, loss,
                        accumulate, dp);
+    return VG_LAUNCH_RC();
+}
+
+extern "C" int vg_head_backward(const float* p, const void* x, const void* w, void* dx, float* dw, float* dlogit, int B,
+                                int groups, float target0, float target1, float gscale, float* loss, int accumulate_loss,
+                                int accumulate_dw, int K, int C, int HW, int dtype, void* stream) {
+    CHECK_DT();
+    VG_CHECK_ARG(p && x && w && loss && B > 0 && (groups == 1 || groups == 2) && K > 0 && C > 0 && HW > 0 && C * HW == K, VG_EINVAL);
+    VG_CHECK_ARG(K % 4 == 0, VG_EALIGN);
+    VG_CHECK_ARG(B * groups <= HB_MAXROWS, VG_ENOSUP);
+    DISPATCH_DT(head_bwd_kernel, dim3((K + 63) / 64), dim3(1024), vg_stream(stream), p, x, w, dx, dw, dlogit, B, groups,
+                target0, target1, gscale, loss, accumulate_loss, accumulate_dw, K, C, HW);
     return VG_LAUNCH_RC();
 }
 

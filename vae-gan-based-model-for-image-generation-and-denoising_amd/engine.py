@@ -437,12 +437,16 @@ class StackEngine:
         return out
 
     def backward(self, ctxpack, dout: torch.Tensor, need_dx: bool, sink: GradSink, param_grads: bool = True,
-                 on_grads=None):
+                 on_grads=None, head_loss=None):
         """dout: gradient w.r.t. forward()'s output.  Returns the gradient w.r.t. the NHWC input (or None).
         param_grads=False skips every weight/bias/BN-parameter gradient (legal when the caller discards
         them, e.g. the generator-loss pass through the discriminator).
         on_grads(i): called right after every parameter gradient of stage i has been enqueued (stages run
         last-to-first) -- the data-parallel trainer launches a gradient bucket's all-reduce from it.
+        head_loss = (target0, target1, groups, gscale, loss_slot, accumulate): instead of `dout`, for a stack that ends
+        in the Discriminator's head -- the BCE of its output probabilities against target0 (first group of rows) / target1
+        (second group), its gradient, the sigmoid backward and the head's data / weight gradients run as ONE launch
+        (ops.head_backward; vaegan_code.py:99-104, :115); loss_slot[0] (+)= the loss.
         Everything runs on the current stream: forking weight gradients onto a second stream (three schedules, rounds 1
         and 2) measured slower every time and is gone ("Concurrency does not pay")."""
         ctx, B, train = ctxpack
@@ -455,6 +459,15 @@ class StackEngine:
         for i in range(len(self.stages) - 1, -1, -1):
             st, c = self.stages[i], ctx[i]
             want_dx = need_dx or i > 0
+            if st.kind == "head" and head_loss is not None:
+                K = st.hin * st.hin * G.padc(st.cin, dt)
+                t0, t1, grp, gscale, slot, acc_loss = head_loss
+                gw, acc = sink.get(st.conv.weight) if param_grads else (None, False)
+                dA = ops.head_backward(c["p"], c["x"], packs[i]["fprop"], B // grp, grp, t0, t1, gscale, slot, acc_loss, gw,
+                                       acc, K, G.padc(st.cin, dt), st.hin * st.hin, dt, want_dx)
+                if param_grads and on_grads is not None:
+                    on_grads(i)
+                continue
             if st.kind == "head":
                 K = st.hin * st.hin * G.padc(st.cin, dt)
                 dx, dlogit = ops.dot_sigmoid_backward(c["p"], dA, packs[i]["fprop"], B, K, dt, want_dx, c["x"])

@@ -754,6 +754,23 @@ def dot_wgrad(x, dlogit, dw, B, K, C, HW, accumulate, dtype):
                                   1 if accumulate else 0, dtype, L.stream_ptr()), "vg_dot_wgrad")
 
 
+HEAD_BWD_MAXROWS = 4096
+
+
+def head_backward(p, x, w, B, groups, target0, target1, gscale, loss, accumulate_loss, dw, accumulate_dw, K, C, HW, dtype,
+                  need_dx):
+    """BCE(sigmoid(head)) backward in one launch (vg_head_backward): p [groups*B] probabilities, x the head's input
+    [groups*B, K] (NHWC-flattened), w its packed weight [K]; loss[0] (+)= the groups' BCE means; returns dx (or None);
+    dw (f32, reference layout, or None) (+)= the weight gradient.  Bit-identical to bce[_pair]_forward_backward +
+    dot_sigmoid_backward + dot_wgrad."""
+    _need_cuda(p, x, w, loss, dw)
+    dx = torch.empty_like(x) if need_dx else None
+    L.check(L.load().vg_head_backward(p.data_ptr(), x.data_ptr(), w.data_ptr(), L.ptr(dx), L.ptr(dw), 0, B, groups,
+                                      target0, target1, gscale, loss.data_ptr(), 1 if accumulate_loss else 0,
+                                      1 if accumulate_dw else 0, K, C, HW, dtype, L.stream_ptr()), "vg_head_backward")
+    return dx
+
+
 def bce_forward_backward(p, target, gscale, loss, accumulate, want_grad, out=None):
     _need_cuda(p, loss, out)
     B = p.numel()

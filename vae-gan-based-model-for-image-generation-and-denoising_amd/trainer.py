@@ -48,6 +48,9 @@ class VAEGANTrainer:
         # next opt_Dis.zero_grad() discards unread.  False = compute them anyway (what the reference executes).
         self.elide_dead_grads = elide_dead_grads
         self.group_d_passes = group_d_passes       # run a D iteration's real+fake passes as one 2B-row launch chain
+        # BCE + its gradient + the sigmoid / head backward as ONE launch per Discriminator pass (ops.head_backward;
+        # bit-identical to the three separate launches, which False selects)
+        self.fuse_head_backward = True
         self.reducer = reducer
         # sync_bn: BatchNorm statistics over the global batch of all ranks (ddp.py) -- an N-rank step then equals
         # the reference's single-process step on the concatenated batch.  Off: per-replica statistics.
@@ -94,7 +97,7 @@ class VAEGANTrainer:
         opts = tuple((o.lr, o.betas, o.eps, o.grad_scale, o.flat_p.data_ptr()) for o in (self.opt_E, self.opt_G, self.opt_D))
         return (tuple(real.shape), float(self.alpha_kl * min(1.0, epoch / 50)), inject, self.E.training, self.G.training,
                 self.D.training, self.alpha_adv, self.sigma, self.real_label, self.fake_label, self.d_iters,
-                self.elide_dead_grads, self.group_d_passes, id(self.reducer), self.sync_bn, opts,
+                self.elide_dead_grads, self.group_d_passes, self.fuse_head_backward, id(self.reducer), self.sync_bn, opts,
                 None if self.noise is None or inject else self.noise.state.data_ptr())
 
     # ---- data-parallel gradient hand-off (ddp.GradReducer) -------------------------------------------------------
@@ -193,6 +196,7 @@ class VAEGANTrainer:
                 recon = ops.nhwc_to_nchw(pre, Gn.nc, dt, apply_tanh=True)
                 ops.nchw_to_nhwc(recon, CP, dt, eps=eps_recon, sigma=self.sigma, out=recon_noisy)
         grouped = self.group_d_passes and D._engine.can_group(B, 2, both)
+        fused_head = self.fuse_head_backward and 2 * B <= ops.HEAD_BWD_MAXROWS and D._engine.stages[-1].kind == "head"
 
         # ---- Discriminator updates (:95-105) ----
         for it in range(self.d_iters):
@@ -200,9 +204,14 @@ class VAEGANTrainer:
             self.opt_D.zero_grad(memset=False)
             if grouped:
                 p_both, c_both = D.engine_forward(both, B, groups=2)                           # .detach(): no dx below
-                dp = torch.empty_like(p_both)
-                ops.bce_pair_forward_backward(p_both, self.real_label, self.fake_label, 1.0, slot, dp)   # :98-103, one launch
-                D._engine.backward(c_both, dp, False, sink, on_grads=self._grad_hook(self.opt_D, D))
+                if fused_head:
+                    # :98-104: the two BCE terms, their gradient and the head's backward in one launch
+                    D._engine.backward(c_both, None, False, sink, on_grads=self._grad_hook(self.opt_D, D),
+                                       head_loss=(self.real_label, self.fake_label, 2, 1.0, slot, False))
+                else:
+                    dp = torch.empty_like(p_both)
+                    ops.bce_pair_forward_backward(p_both, self.real_label, self.fake_label, 1.0, slot, dp)   # :98-103
+                    D._engine.backward(c_both, dp, False, sink, on_grads=self._grad_hook(self.opt_D, D))
             else:
                 p_real, c_real = D.engine_forward(real_noisy, B)
                 p_fake, c_fake = D.engine_forward(recon_noisy, B)
@@ -217,12 +226,15 @@ class VAEGANTrainer:
         p_adv, c_adv = D.engine_forward(recon_noisy, B)
         d_recon = ops.mse_forward_backward(recon, real, 1.0, losses[0:1], True)               # :113
         ops.kl_forward(mulv, lvc, L, float(B), dt, out=losses[1:2])                           # :114
-        dp_adv = ops.bce_forward_backward(p_adv, self.real_label, self.alpha_adv, losses[2:3], False, True)  # :115
+        dp_adv = None
+        if not fused_head:
+            dp_adv = ops.bce_forward_backward(p_adv, self.real_label, self.alpha_adv, losses[2:3], False, True)  # :115
 
         # ---- backward of total = recon + a_kl*min(1,epoch/50)*kl + a_adv*adv, then E and G steps (:131-135) ----
         self.opt_E.zero_grad(memset=False)
         self.opt_G.zero_grad(memset=False)
-        d_noisy = D._engine.backward(c_adv, dp_adv, True, sink, param_grads=not self.elide_dead_grads)
+        d_noisy = D._engine.backward(c_adv, dp_adv, True, sink, param_grads=not self.elide_dead_grads,
+                                     head_loss=(self.real_label, 0.0, 1, self.alpha_adv, losses[2:3], False) if fused_head else None)
         # d total / d recon = d MSE + d adv through the instance-noise add (:92), then through tanh: one pass
         d_pre = ops.nchw_grad_add_to_nhwc(d_recon, d_noisy, recon, G.padc(Gn.nc, dt), dt)
         dz = Gn._engine.backward(ctxG, d_pre, True, sink, on_grads=self._grad_hook(self.opt_G, Gn))
