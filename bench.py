@@ -93,7 +93,12 @@ def cpu_baseline(S, B, budget_s=20.0):
     BASELINE.md section 3).  Reported baseline only."""
     import vaegan_ref as R
     model, avail, total = cpu_info()
-    cores = max(1, min(avail, 32))            # ATen's CPU conv kernels stop scaling (and oversubscribe) beyond this
+    # Threads: measured on the GPU box (tools/cpu_cores_probe.py, round 3; EPYC 9575F, 256 hardware threads visible, S=64
+    # B=128 fp32 step of this oracle): 8 threads 103.6 img/s, 16: 101.8, 32: 87.2, 64: 48.2, 128: 22.3, 256: 1.3 -- ATen's CPU
+    # conv / BatchNorm kernels stop scaling at ~8-16 threads at these sizes and collapse when oversubscribed, so
+    # torch.set_num_threads(os.cpu_count()) (BASELINE.md section 3) would report 1 % of what the host can do.  16 is used;
+    # `cores` says so and `cores_available` what the box has.
+    cores = max(1, min(avail, 16))
     torch.set_num_threads(cores)
 
     def sample(S_, B_, budget):
@@ -111,6 +116,8 @@ def cpu_baseline(S, B, budget_s=20.0):
     dt, steps = sample(S, B, budget_s)
     out = {"value": round(B / dt, 2), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
            "cpu_model": model, "cores_available": avail, "cores_total": total,
+           "cores_note": "thread count with the best measured throughput of this oracle on this host class "
+                         "(8: 103.6, 16: 101.8, 32: 87.2, 64: 48.2, 128: 22.3, 256: 1.3 img/s; tools/cpu_cores_probe.py)",
            "sample": f"{steps} full training steps of S={S} B={B} fp32 after 1 warm-up, CPU oracle "
                      f"(oracle/vaegan_ref.py, same ATen CPU kernels the reference executes)",
            "s_per_step": round(dt, 3)}
