@@ -37,7 +37,9 @@ for name, net, i, what, mult in (("G.last fprop", g, len(g._engine.stages) - 1, 
         res["tnconv"] = timeit(lambda: ops.tnconv(tn[0], X, packs[i]["tn_" + what], alg=(fl, by)), "edge")
     for env in ("1", "0"):
         os.environ["VG_EDGE"] = env
+        ops.reload_switches()                      # the library reads its switches once, at load
         bias = packs[i]["bias"] if what == "fprop" else None
         res["gather_gemm VG_EDGE=" + env] = timeit(lambda: ops.gather_gemm(gg, X, packs[i][what], dt, bias=bias, want_stats=(st.bn is not None and what == "fprop"), alg=(fl, by)), None)
     os.environ["VG_EDGE"] = "1"
+    ops.reload_switches()
     print(f"{name:14s} B={Bx:4d} alg {by/1e6:7.1f} MB {fl/1e9:6.2f} GF | " + " | ".join(f"{k}: " + ", ".join(f"{f} {t:.1f}us x{n}" for f, (t, n) in v.items()) for k, v in res.items()), flush=True)
