@@ -228,7 +228,9 @@ def test_layout_noise_tanh(ops, dtype):
                                             (32, 3, 4, 2, 1, 64, 2),
                                             (64, 3, 3, 1, 1, 16, 1),      # whole image in one tile
                                             (64, 1, 4, 2, 1, 48, 2),      # N=1, rows that do not fill the last tile
-                                            (32, 4, 4, 2, 1, 16, 1)])     # K*K*N = 64: all four column tiles
+                                            (32, 4, 4, 2, 1, 16, 1),      # K*K*N = 64: all four column tiles
+                                            (16, 3, 3, 1, 1, 64, 2),      # C = 16 (the 16-channel members at S=256): half a
+                                            (16, 3, 4, 2, 1, 32, 2)])     # 32-channel chunk per pixel, zero weight rows beyond
 def test_edge_layer_transposed_conv_vs_torch(ops, C, N, k, s, p, H, B):
     """vg_tnconv (GEMM per input pixel + col2im, csrc/edge_conv.hip) against torch's conv_transpose2d in fp64 on the
     bf16-rounded operands: plain NHWC output, then the fused Tanh / NCHW image / instance-noise epilogue."""
@@ -260,7 +262,7 @@ def test_edge_layer_transposed_conv_vs_torch(ops, C, N, k, s, p, H, B):
 
 
 def test_edge_layer_kernel_rejects_what_it_does_not_take(ops):
-    assert G.tn_spec(2, 64, 64, 16, 3, 3, 1, 1, G.BF16, 9, 27) is None          # C = 16 (S=256 members): gather-GEMM
+    assert G.tn_spec(2, 256, 256, 16, 3, 3, 1, 1, G.BF16, 9, 27) is None        # three 256-pixel rows do not fit one tile: gather-GEMM
     assert G.tn_spec(2, 64, 64, 64, 3, 3, 1, 1, G.F32, 9, 27) is None           # exact-f32 parity path: gather-GEMM
     assert G.tn_spec(2, 64, 64, 64, 8, 3, 1, 1, G.BF16, 9, 72) is None          # not narrow
     assert G.tn_spec(2, 31, 31, 64, 3, 3, 1, 1, G.BF16, 9, 27) is None          # rows are not whole 16-pixel groups
@@ -275,7 +277,10 @@ def test_edge_layer_kernel_rejects_what_it_does_not_take(ops):
                                               ("conv", 32, 4, 2, 0, 64, 2),    # Encoder's first layer: 31x31 outputs, p=0
                                               ("conv", 32, 4, 2, 1, 128, 1),   # S=128 members
                                               ("convT", 32, 3, 1, 1, 128, 1),
-                                              ("conv", 64, 4, 2, 1, 16, 5)])   # many images per workgroup walk, tiny maps
+                                              ("conv", 64, 4, 2, 1, 16, 5),    # many images per workgroup walk, tiny maps
+                                              ("conv", 16, 4, 2, 1, 256, 1),   # S=256 members: 16 channels on the wide side
+                                              ("convT", 16, 3, 1, 1, 256, 1),  # (gan_code.py:49 and :61 as written)
+                                              ("conv", 16, 4, 2, 1, 32, 3)])
 def test_edge_layer_weight_gradient_vs_torch(ops, kind, C, k, s, p, H, B):
     """vg_edge_wgrad (transposed LDS reads of both operands, narrow operand read straight from the image patch) against
     torch's convolution weight gradient in fp64 on the bf16-rounded operands; plain and accumulating."""

@@ -62,8 +62,11 @@ __global__ __launch_bounds__(256) void tnconv_kernel(const vg_tn_desc d, const i
 
     // ---- GEMM over the tile's pixels: 16 pixels per MFMA row group; ALL of a wave's groups (<= 8: 16 x 16-byte
     //      loads per lane) are in flight at once -- the only latency the workgroup exposes is one HBM round trip ----
+    // one pixel = C bf16 = pixb bytes (C = 16: half a 32-channel chunk -- the lanes of its upper half load nothing and
+    // multiply zero weight rows: S >= 128 members of the size family, gan_code.py:46-49 / :61-66)
+    const int pixb = d.C * 2;
     const unsigned char* Xb = reinterpret_cast<const unsigned char*>(d.X) +
-                              ((int64_t)(b * d.IH + iy_lo) * d.IW) * (int64_t)(KC * 64);
+                              ((int64_t)(b * d.IH + iy_lo) * d.IW) * (int64_t)pixb;
     const int ngroups = npix >> 4;
     constexpr int U = NPIX / 64;                              // groups per wave
     {
@@ -74,7 +77,8 @@ __global__ __launch_bounds__(256) void tnconv_kernel(const vg_tn_desc d, const i
             for (int kc = 0; kc < KC; ++kc) {
                 const int g = wave * U + u;
                 u32x4 v = {0u, 0u, 0u, 0u};
-                if (g < ngroups) v = *reinterpret_cast<const u32x4*>(Xb + (int64_t)(g * 16 + fr) * (KC * 64) + kc * 64 + fg * 16);
+                if (g < ngroups && kc * 32 + fg * 8 < d.C)
+                    v = *reinterpret_cast<const u32x4*>(Xb + (int64_t)(g * 16 + fr) * pixb + kc * 64 + fg * 16);
                 a[u][kc] = v;
             }
 #pragma unroll
@@ -154,8 +158,8 @@ inline int tn_plan(const vg_tn_desc* d, TnPlan* p) {
     VG_CHECK_ARG(d->B > 0 && d->IH > 0 && d->IW > 0 && d->P >= 0, VG_EINVAL);
     VG_CHECK_ARG((d->K == 3 && d->S == 1) || (d->K == 4 && d->S == 2), VG_ENOSUP);      // the two edge-layer forms
     VG_CHECK_ARG(d->N >= 1 && d->N <= 4 && d->OC == 8, VG_ENOSUP);
-    VG_CHECK_ARG(d->C == 32 || d->C == 64, VG_ENOSUP);
-    VG_CHECK_ARG(d->Wpitch >= d->C && d->Wpitch % 8 == 0, VG_EALIGN);
+    VG_CHECK_ARG(d->C == 16 || d->C == 32 || d->C == 64, VG_ENOSUP);
+    VG_CHECK_ARG(d->Wpitch >= ((d->C + 31) / 32) * 32 && d->Wpitch % 8 == 0, VG_EALIGN);     // whole 32-channel chunks (zero-padded)
     VG_CHECK_ARG(d->OH == (d->IH - 1) * d->S - 2 * d->P + d->K && d->OW == (d->IW - 1) * d->S - 2 * d->P + d->K, VG_EINVAL);
     VG_CHECK_ARG(vg_aligned16(d->X) && vg_aligned16(d->Wp) && vg_aligned16(d->Y), VG_EALIGN);
     VG_CHECK_ARG(d->act == VG_ACT_NONE || d->act == VG_ACT_TANH, VG_EINVAL);
@@ -163,7 +167,7 @@ inline int tn_plan(const vg_tn_desc* d, TnPlan* p) {
     const int NJ = d->K * d->K * d->N;
     VG_CHECK_ARG(NJ <= 64, VG_ENOSUP);
     p->NT = (NJ + 15) / 16;
-    p->KC = d->C / 32;
+    p->KC = (d->C + 31) / 32;
     // product tile in LDS: NT*16 columns x NPIX pixels of f32; keep it <= ~66 KB so that two workgroups share a CU
     // (one's HBM loads under the other's col2im): 512 pixels for <= 32 columns, 256 beyond
     p->NPIX = p->NT <= 2 ? 512 : 256;
@@ -214,7 +218,7 @@ constexpr int EW_TP = 256;                 // wide pixels per tile
 
 typedef __attribute__((ext_vector_type(4))) __bf16 ew_bf16x4;
 
-template <int CT>                          // C = 16 * CT channels of the wide operand (CT = 2 | 4)
+template <int CT>                          // C = 16 * CT channels of the wide operand (CT = 1 | 2 | 4)
 __global__ __launch_bounds__(256) void edge_wgrad_kernel(const vg_ew_desc d, const int R, const int tiles_per_img,
                                                          const int ntiles, const int JT) {
     constexpr int RB = CT * 32;                                   // bytes per wide pixel
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(256) void edge_wgrad_kernel(const vg_ew_desc d, con
             for (int it = 0; it < EW_TP / PPI / 4; ++it) {
                 const int i0 = (it * 4 + wave_u) * PPI;            // first pixel of this wave instruction
                 const int pix = i0 + lane / UPP, u = lane % UPP;
-                const int f = CT == 4 ? ((pix >> 1) & 3) : ((pix >> 2) & 1);
+                const int f = CT == 4 ? ((pix >> 1) & 3) : CT == 2 ? ((pix >> 2) & 1) : 0;     // (C = 16: one 32-byte block, no swizzle)
                 const int su = (((u >> 1) ^ f) << 1) | (u & 1);    // source unit that belongs at LDS unit u
                 const unsigned char* src = pix < npix ? base + (int64_t)pix * RB + su * 16 : Zp;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -293,8 +297,8 @@ __global__ __launch_bounds__(256) void edge_wgrad_kernel(const vg_ew_desc d, con
                 const ew_bf16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) ew_bf16x4*)a0);
                 const ew_bf16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) ew_bf16x4*)a1);
                 const bf16x8 af = __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7);
-                const int f0 = CT == 4 ? ((r0 >> 1) & 3) : ((r0 >> 2) & 1);
-                const int f1 = CT == 4 ? ((r1 >> 1) & 3) : ((r1 >> 2) & 1);
+                const int f0 = CT == 4 ? ((r0 >> 1) & 3) : CT == 2 ? ((r0 >> 2) & 1) : 0;
+                const int f1 = CT == 4 ? ((r1 >> 1) & 3) : CT == 2 ? ((r1 >> 2) & 1) : 0;
 #pragma unroll
                 for (int c = 0; c < CT; ++c) {
                     const unsigned char* b0 = wide + r0 * RB + ((c ^ f0) << 5) + 8 * p;
@@ -362,7 +366,7 @@ struct EwPlan { int R, tiles_per_img, ntiles, JT, CT, grid; int64_t ws_bytes; };
 inline int ew_plan(const vg_ew_desc* d, EwPlan* p) {
     VG_CHECK_ARG(d != nullptr, VG_EINVAL);
     VG_CHECK_ARG(d->B > 0 && d->WH > 0 && d->WW > 0 && d->NH > 0 && d->NW > 0 && d->P >= 0, VG_EINVAL);
-    VG_CHECK_ARG(d->C == 32 || d->C == 64, VG_ENOSUP);
+    VG_CHECK_ARG(d->C == 16 || d->C == 32 || d->C == 64, VG_ENOSUP);
     VG_CHECK_ARG(d->N >= 1 && d->N <= 3, VG_ENOSUP);              // channel 3 of the narrow operand must be the zero pad
     VG_CHECK_ARG((d->K == 3 || d->K == 4) && (d->S == 1 || d->S == 2), VG_ENOSUP);
     VG_CHECK_ARG(d->WW <= EW_TP, VG_ENOSUP);
@@ -417,6 +421,7 @@ extern "C" int vg_edge_wgrad(const vg_ew_desc* d, void* stream) {
     VG_CHECK_ARG(d->ws_bytes >= p.ws_bytes, VG_EINVAL);
     hipStream_t s = vg_stream(stream);
     if (p.CT == 4) vg_launch_timed(1, edge_wgrad_kernel<4>, dim3(p.grid), dim3(256), 0, s, *d, p.R, p.tiles_per_img, p.ntiles, p.JT);
+    else if (p.CT == 1) vg_launch_timed(1, edge_wgrad_kernel<1>, dim3(p.grid), dim3(256), 0, s, *d, p.R, p.tiles_per_img, p.ntiles, p.JT);
     else vg_launch_timed(1, edge_wgrad_kernel<2>, dim3(p.grid), dim3(256), 0, s, *d, p.R, p.tiles_per_img, p.ntiles, p.JT);
     rc = VG_LAUNCH_RC();
     if (rc) return rc;

@@ -172,7 +172,7 @@ class TNSpec:
 def tn_spec(B, h, w, C, N, k, s, p, dtype, s_n, s_c):
     """-> (TNSpec, PackSpec) or None when vg_tnconv does not take the shape (the gather-GEMM form is used then).
     s_n / s_c: element strides of the n / c index in the [c][n][k][k]-ordered weight."""
-    if dtype != BF16 or C not in (32, 64) or N > 4 or k * k * N > 64 or (k, s) not in ((3, 1), (4, 2)):
+    if dtype != BF16 or C not in (16, 32, 64) or N > 4 or k * k * N > 64 or (k, s) not in ((3, 1), (4, 2)):
         return None
     npix = 512 if (k * k * N + 15) // 16 <= 2 else 256     # input pixels per workgroup tile (csrc/edge_conv.hip: tn_plan)
     if w % 16 != 0 or w > npix or h != w:
@@ -211,7 +211,7 @@ class EWSpec:
 
 def edge_wgrad_spec(B, wh, ww, C, nh, nw, N, k, s, p, dtype, s_c, s_n):
     """-> EWSpec or None when the edge-layer weight-gradient kernel does not take the shape."""
-    if dtype != BF16 or C not in (32, 64) or N > 3 or k not in (3, 4) or s not in (1, 2) or ww > 256:
+    if dtype != BF16 or C not in (16, 32, 64) or N > 3 or k not in (3, 4) or s not in (1, 2) or ww > 256:
         return None
     R = 256 // ww
     while R > 1 and (((R - 1) * s + k) * ((ww - 1) * s + k) + 1) * 16 > 22 * 1024:
