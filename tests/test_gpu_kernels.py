@@ -230,7 +230,10 @@ def test_layout_noise_tanh(ops, dtype):
                                             (64, 1, 4, 2, 1, 48, 2),      # N=1, rows that do not fill the last tile
                                             (32, 4, 4, 2, 1, 16, 1),      # K*K*N = 64: all four column tiles
                                             (16, 3, 3, 1, 1, 64, 2),      # C = 16 (the 16-channel members at S=256): half a
-                                            (16, 3, 4, 2, 1, 32, 2)])     # 32-channel chunk per pixel, zero weight rows beyond
+                                            (16, 3, 4, 2, 1, 32, 2),      # 32-channel chunk per pixel, zero weight rows beyond
+                                            (16, 3, 3, 1, 1, 256, 1),     # S=256: the Generator's last layer as written (gan_code.py:49),
+                                            (16, 3, 4, 2, 1, 128, 1),     # the image gradient below gan_code.py:61 -- column-block tiles
+                                            (32, 2, 3, 1, 1, 192, 1)])    # a width that is no power of two
 def test_edge_layer_transposed_conv_vs_torch(ops, C, N, k, s, p, H, B):
     """vg_tnconv (GEMM per input pixel + col2im, csrc/edge_conv.hip) against torch's conv_transpose2d in fp64 on the
     bf16-rounded operands: plain NHWC output, then the fused Tanh / NCHW image / instance-noise epilogue."""
@@ -262,7 +265,7 @@ def test_edge_layer_transposed_conv_vs_torch(ops, C, N, k, s, p, H, B):
 
 
 def test_edge_layer_kernel_rejects_what_it_does_not_take(ops):
-    assert G.tn_spec(2, 256, 256, 16, 3, 3, 1, 1, G.BF16, 9, 27) is None        # three 256-pixel rows do not fit one tile: gather-GEMM
+    assert G.tn_spec(2, 40, 40, 16, 3, 3, 1, 1, G.BF16, 9, 27) is None          # rows are not whole 16-pixel groups
     assert G.tn_spec(2, 64, 64, 64, 3, 3, 1, 1, G.F32, 9, 27) is None           # exact-f32 parity path: gather-GEMM
     assert G.tn_spec(2, 64, 64, 64, 8, 3, 1, 1, G.BF16, 9, 72) is None          # not narrow
     assert G.tn_spec(2, 31, 31, 64, 3, 3, 1, 1, G.BF16, 9, 27) is None          # rows are not whole 16-pixel groups

@@ -31,20 +31,29 @@ __device__ __forceinline__ int fdiv(int a, int b, float inv) {
 // NT 16-column tiles of j (K*K*N <= 16*NT), KC 32-channel chunks (C = 32*KC), NPIX input pixels (halo rows included)
 // per workgroup, K x K taps at stride S (compile time: the col2im loop unrolls to its 9 | 4 live taps, no divisions)
 template <int NT, int KC, int NPIX, int K, int S>
-__global__ __launch_bounds__(256) void tnconv_kernel(const vg_tn_desc d, const int RO, const int tiles_y) {
+__global__ __launch_bounds__(256) void tnconv_kernel(const vg_tn_desc d, const int RO, const int tiles_y, const int CO,
+                                                     const int tiles_x, const int TC) {
+    // Tile: output rows [oy_a, oy_b) x output columns [ox_a, ox_b); its input window is nrows x TC pixels (TC a multiple of
+    // 16: whole MFMA row groups per window row) starting at column c0.  tiles_x == 1: TC = IW, whole rows (every map up to
+    // 128 pixels wide); wider maps (S=256 members) are cut into column blocks with a K-1 halo on either side.
     constexpr int PS = NPIX + 4;                              // LDS row pitch of the product tile (floats)
     __shared__ __attribute__((aligned(16))) float Pm[NT * 16 * PS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
-    const int b = blockIdx.x / tiles_y, ty = blockIdx.x - b * tiles_y;
+    const int txy = tiles_x * tiles_y;
+    const int b = blockIdx.x / txy, tr = blockIdx.x - b * txy;
+    const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
     const int oy_a = ty * RO, oy_b = min(d.OH, oy_a + RO);
+    const int ox_a = tx * CO, ox_b = min(d.OW, ox_a + CO);
+    int c0 = ox_a + d.P - (K - 1);
+    c0 = c0 <= 0 ? 0 : (c0 + S - 1) / S;                      // first input column that contributes
     // input rows that contribute to output rows [oy_a, oy_b)
     int iy_lo = oy_a + d.P - (K - 1);
     iy_lo = iy_lo <= 0 ? 0 : (iy_lo + S - 1) / S;
     int iy_hi = (oy_b - 1 + d.P) / S;                         // inclusive
     iy_hi = min(iy_hi, d.IH - 1);
     const int nrows = iy_hi - iy_lo + 1;
-    const int npix = nrows * d.IW;                            // <= NPIX (host), multiple of 16 (IW % 16 == 0)
+    const int npix = nrows * TC;                              // <= NPIX (host), multiple of 16 (TC % 16 == 0)
     const int NJ = K * K * d.N;
 
     // ---- B fragments: Wp[j][c] (bf16, row pitch Wpitch), zero rows beyond NJ ----
@@ -68,6 +77,7 @@ __global__ __launch_bounds__(256) void tnconv_kernel(const vg_tn_desc d, const i
     const unsigned char* Xb = reinterpret_cast<const unsigned char*>(d.X) +
                               ((int64_t)(b * d.IH + iy_lo) * d.IW) * (int64_t)pixb;
     const int ngroups = npix >> 4;
+    const float inv_tc = 1.0f / (float)TC;
     constexpr int U = NPIX / 64;                              // groups per wave
     {
         u32x4 a[U][KC];
@@ -76,9 +86,11 @@ __global__ __launch_bounds__(256) void tnconv_kernel(const vg_tn_desc d, const i
 #pragma unroll
             for (int kc = 0; kc < KC; ++kc) {
                 const int g = wave * U + u;
+                const int t = g * 16 + fr;                    // pixel of the window: row t / TC, column c0 + t % TC
+                const int wr = fdiv(t, TC, inv_tc), gx = c0 + t - wr * TC;
                 u32x4 v = {0u, 0u, 0u, 0u};
-                if (g < ngroups && kc * 32 + fg * 8 < d.C)
-                    v = *reinterpret_cast<const u32x4*>(Xb + (int64_t)(g * 16 + fr) * pixb + kc * 64 + fg * 16);
+                if (g < ngroups && gx < d.IW && kc * 32 + fg * 8 < d.C)
+                    v = *reinterpret_cast<const u32x4*>(Xb + ((int64_t)wr * d.IW + gx) * pixb + kc * 64 + fg * 16);
                 a[u][kc] = v;
             }
 #pragma unroll
@@ -100,15 +112,17 @@ __global__ __launch_bounds__(256) void tnconv_kernel(const vg_tn_desc d, const i
     __syncthreads();
 
     // ---- col2im + epilogue: one output pixel per thread and pass, taps summed in fixed (kh, kw) order ----
-    const int count = (oy_b - oy_a) * d.OW;
-    const float inv_ow = 1.0f / (float)d.OW;
+    const int cw = ox_b - ox_a;                               // output columns of this tile
+    const int count = (oy_b - oy_a) * cw;
+    const float inv_cw = 1.0f / (float)cw;
+    const int ix_end = min(d.IW, c0 + TC);                    // input columns [c0, ix_end) are in the window
     const NoiseSrc nz{d.eps, reinterpret_cast<const unsigned long long*>(d.rng), (uint32_t)d.draw};
     const bool noisy = d.eps != nullptr || d.rng != nullptr;
     unsigned char* Yb = reinterpret_cast<unsigned char*>(d.Y);
     const int N = d.N;
     for (int q = tid; q < count; q += 256) {
-        const int oyl = fdiv(q, d.OW, inv_ow);
-        const int ox = q - oyl * d.OW, oy = oy_a + oyl;
+        const int oyl = fdiv(q, cw, inv_cw);
+        const int ox = ox_a + q - oyl * cw, oy = oy_a + oyl;
         float v[4] = {0.f, 0.f, 0.f, 0.f};                    // N <= 4 output channels
 #pragma unroll
         for (int kh = 0; kh < K; ++kh) {
@@ -119,8 +133,8 @@ __global__ __launch_bounds__(256) void tnconv_kernel(const vg_tn_desc d, const i
             for (int kw = 0; kw < K; ++kw) {
                 const int s = ox + d.P - kw;
                 const int ix = S == 2 ? (s >> 1) : s;
-                if (yok && s >= 0 && !(S == 2 && (s & 1)) && ix < d.IW) {
-                    const float* src = &Pm[((kh * K + kw) * N) * PS + (iy - iy_lo) * d.IW + ix];
+                if (yok && s >= 0 && !(S == 2 && (s & 1)) && ix < ix_end) {
+                    const float* src = &Pm[((kh * K + kw) * N) * PS + (iy - iy_lo) * TC + (ix - c0)];
 #pragma unroll
                     for (int n = 0; n < 4; ++n)
                         if (n < N) v[n] += src[n * PS];
@@ -150,7 +164,7 @@ __global__ __launch_bounds__(256) void tnconv_kernel(const vg_tn_desc d, const i
     }
 }
 
-struct TnPlan { int RO, tiles_y, NT, KC, NPIX; };
+struct TnPlan { int RO, tiles_y, NT, KC, NPIX, CO, tiles_x, TC; };
 
 inline int tn_plan(const vg_tn_desc* d, TnPlan* p) {
     VG_CHECK_ARG(d != nullptr, VG_EINVAL);
@@ -171,28 +185,58 @@ inline int tn_plan(const vg_tn_desc* d, TnPlan* p) {
     // product tile in LDS: NT*16 columns x NPIX pixels of f32; keep it <= ~66 KB so that two workgroups share a CU
     // (one's HBM loads under the other's col2im): 512 pixels for <= 32 columns, 256 beyond
     p->NPIX = p->NT <= 2 ? 512 : 256;
-    VG_CHECK_ARG(d->IW % 16 == 0 && d->IW <= p->NPIX, VG_ENOSUP);
-    // largest block of output rows (a multiple of S) whose input rows, halo included, fit the tile
-    const int max_rows = p->NPIX / d->IW;
-    int RO = 0;
-    for (int r = d->S; r <= d->OH + d->S; r += d->S) {
-        const int need = (r - 1 + d->K - 1) / d->S + 1;      // input rows touched by r consecutive output rows (worst phase)
-        if (need > max_rows) break;
-        RO = r;
+    VG_CHECK_ARG(d->IW % 16 == 0, VG_ENOSUP);
+    // Window of input pixels per workgroup: nrows x TC <= NPIX with TC a multiple of 16.  Whole rows (TC = IW) when at
+    // least the rows behind one block of S output rows fit; otherwise (maps wider than ~128 pixels) column blocks.  Among
+    // the candidates the one with the least halo overhead (window pixels per output pixel) wins.
+    auto rows_for = [&](int tc) { return p->NPIX / tc; };
+    auto ro_for = [&](int max_rows) {               // largest block of output rows (a multiple of S) whose input rows fit
+        int RO = 0;
+        for (int r = d->S; r <= d->OH + d->S; r += d->S) {
+            const int need = (r - 1 + d->K - 1) / d->S + 1;  // input rows touched by r consecutive output rows (worst phase)
+            if (need > max_rows) break;
+            RO = r;
+        }
+        return RO;
+    };
+    auto co_for = [&](int tc) {                     // largest block of output columns (a multiple of S) behind tc input columns
+        int CO = 0;
+        for (int c = d->S; c <= d->OW + d->S; c += d->S) {
+            const int need = (c - 1 + d->K - 1) / d->S + 1;
+            if (need > tc) break;
+            CO = c;
+        }
+        return CO;
+    };
+    int best_tc = 0, best_ro = 0, best_co = 0;
+    double best_cost = 1e30;
+    for (int tc = 16; tc <= d->IW && tc <= p->NPIX; tc += 16) {
+        const bool full = tc == d->IW;
+        if (!full && d->IW % tc != 0 && tc * 2 > d->IW) continue;   // (a block that is neither the row nor a sensible fraction)
+        int ro = ro_for(rows_for(tc));
+        int co = full ? d->OW : co_for(tc);
+        if (ro <= 0 || co <= 0) continue;
+        if (ro > d->OH) ro = ((d->OH + d->S - 1) / d->S) * d->S;
+        if (co > d->OW) co = d->OW;
+        const int nrows = (ro - 1 + d->K - 1) / d->S + 1;
+        const double cost = (double)nrows * tc / ((double)ro * co) + (full ? 0.0 : 0.02);   // prefer whole rows on a tie
+        if (cost < best_cost) { best_cost = cost; best_tc = tc; best_ro = ro; best_co = co; }
     }
-    VG_CHECK_ARG(RO > 0, VG_ENOSUP);
-    if (RO > d->OH) RO = ((d->OH + d->S - 1) / d->S) * d->S;
-    p->RO = RO;
-    p->tiles_y = (d->OH + RO - 1) / RO;
+    VG_CHECK_ARG(best_tc > 0, VG_ENOSUP);
+    p->TC = best_tc;
+    p->RO = best_ro;
+    p->CO = best_co;
+    p->tiles_y = (d->OH + p->RO - 1) / p->RO;
+    p->tiles_x = (d->OW + p->CO - 1) / p->CO;
     return 0;
 }
 
 template <int NT, int KC>
 inline void tn_launch(const vg_tn_desc* d, const TnPlan& p, hipStream_t s) {
-    dim3 grid(d->B * p.tiles_y), block(256);
+    dim3 grid(d->B * p.tiles_y * p.tiles_x), block(256);
     constexpr int NPIX = NT <= 2 ? 512 : 256;
-    if (d->K == 3) vg_launch_timed(2, (tnconv_kernel<NT, KC, NPIX, 3, 1>), grid, block, 0, s, *d, p.RO, p.tiles_y);
-    else vg_launch_timed(2, (tnconv_kernel<NT, KC, NPIX, 4, 2>), grid, block, 0, s, *d, p.RO, p.tiles_y);
+    if (d->K == 3) vg_launch_timed(2, (tnconv_kernel<NT, KC, NPIX, 3, 1>), grid, block, 0, s, *d, p.RO, p.tiles_y, p.CO, p.tiles_x, p.TC);
+    else vg_launch_timed(2, (tnconv_kernel<NT, KC, NPIX, 4, 2>), grid, block, 0, s, *d, p.RO, p.tiles_y, p.CO, p.tiles_x, p.TC);
 }
 
 

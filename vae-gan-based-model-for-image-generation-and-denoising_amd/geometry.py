@@ -175,11 +175,11 @@ def tn_spec(B, h, w, C, N, k, s, p, dtype, s_n, s_c):
     if dtype != BF16 or C not in (16, 32, 64) or N > 4 or k * k * N > 64 or (k, s) not in ((3, 1), (4, 2)):
         return None
     npix = 512 if (k * k * N + 15) // 16 <= 2 else 256     # input pixels per workgroup tile (csrc/edge_conv.hip: tn_plan)
-    if w % 16 != 0 or w > npix or h != w:
+    if w % 16 != 0 or h != w:
         return None
     OH, OW = convT_out(h, k, s, p), convT_out(w, k, s, p)
     rows_needed = (s - 1 + k - 1) // s + 1                 # input rows behind the smallest output row block
-    if rows_needed * w > npix:
+    if rows_needed * 16 > npix:                            # (maps wider than the tile are cut into column blocks: tn_plan)
         return None
     Kp = kpad(C, dtype)
     tn = TNSpec(B=B, IH=h, IW=w, C=C, N=N, K=k, S=s, P=p, OH=OH, OW=OW, OC=padc(N, dtype), Wpitch=Kp)
