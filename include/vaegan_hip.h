@@ -48,7 +48,7 @@ extern "C" {
 #define VG_ACT_LRELU   2   /* nn.LeakyReLU(slope)    main_vae.py:25, gan_code.py:62-82 */
 #define VG_ACT_TANH    3   /* nn.Tanh()              gan_code.py:50 (vg_tnconv epilogue only) */
 
-#define VG_ABI_VERSION 8   /* 2: vg_pack_desc.tile_start, SyncBN / WGAN / data-path entry points; 3: in-kernel noise (vg_*_rng);
+#define VG_ABI_VERSION 9   /* 2: vg_pack_desc.tile_start, SyncBN / WGAN / data-path entry points; 3: in-kernel noise (vg_*_rng);
                              4: vg_bn_finalize_act_forward, vg_bn_backward_finalize_apply;
                              7: vg_bce_pair_forward_backward;
                              8: vg_head_backward; round-3 prune -- the opt-in experiments of ABI 5 / 6 that measured slower (input prologue of
@@ -440,6 +440,13 @@ int vg_axpy(const float* a, const float* b, float alpha, float* out, int64_t n, 
 int vg_adam_step(float* p, const float* g, float* m, float* v, int64_t n,
                  double lr, double beta1, double beta2, double eps, float grad_scale,
                  float* state /* [4] device */, void* stream);
+/* A training iteration that steps several optimizers (vaegan_code.py:105, :134-135) can prepare all of them -- step
+ * count + 1, bias corrections -- together with the noise generator's iteration counter (rng may be NULL) in ONE
+ * single-thread launch at its top; vg_adam_step called with lr < 0 then skips its own prepare launch and uses `state` as
+ * it finds it.  Same double arithmetic as the per-optimizer prepare: bit-identical updates. */
+#define VG_PROLOGUE_MAX 4
+int vg_step_prologue(uint64_t* rng, float* const* states, const double* lr, const double* beta1, const double* beta2,
+                     int n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -505,6 +505,34 @@ def test_fused_head_backward_is_bit_identical_to_the_three_launches(dtype, B):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("dtype,B,graphed", [("fp32", 8, False), ("bf16", 128, False), ("bf16", 128, True)])
+def test_step_prologue_is_bit_identical_to_per_optimizer_prepares(dtype, B, graphed):
+    """The noise counter and the three optimizers' step counters / bias corrections prepared by ONE launch at the top of
+    the iteration (ops.step_prologue) against one prepare launch per optimizer.step() (vaegan_code.py:105, :134-135): three
+    (four) iterations, eager and replayed -- every loss, parameter, Adam moment and device-side counter bit for bit."""
+    outs = []
+    for merged in (True, False):
+        e, g, d, tr = build(64, dtype=dtype)
+        tr.fuse_step_prologue = merged
+        fn = tr.train_step_graphed if graphed else tr.train_step
+        ls = []
+        for step in range(4 if graphed else 3):
+            real, ez, er, ec = (t.to(DEV) for t in make_inputs(B, 64, 4500 + step))
+            ls.append(fn(real, 60, ez, er, ec)[:5].clone())
+        torch.cuda.synchronize()
+        outs.append((torch.stack(ls).cpu(), [o.flat_p.cpu().clone() for o in (tr.opt_E, tr.opt_G, tr.opt_D)],
+                     [o.exp_avg.cpu().clone() for o in (tr.opt_E, tr.opt_G, tr.opt_D)],
+                     [o.exp_avg_sq.cpu().clone() for o in (tr.opt_E, tr.opt_G, tr.opt_D)],
+                     [(o.steps, float(o.state_dev[0]), float(o.state_dev[1]), float(o.state_dev[2]))
+                      for o in (tr.opt_E, tr.opt_G, tr.opt_D)]))
+    for it in range(outs[0][0].shape[0]):
+        assert torch.equal(outs[0][0][it], outs[1][0][it]), f"losses of iteration {it + 1} differ: {outs[0][0][it] - outs[1][0][it]}"
+    for k in (1, 2, 3):
+        for a, b in zip(outs[0][k], outs[1][k]):
+            assert torch.equal(a, b)
+    assert outs[0][4] == outs[1][4]
+
+
 class _LocalReducer:
     """world_size-1 stand-in with the whole-buffer GradReducer surface: lets the single GPU exercise the SEGMENTED
     graph path (collectives between hipGraph segments) and records how the trainer drives it."""

@@ -825,6 +825,12 @@ int dispatch(const vg_gg_desc* d, TileCfg t, hipStream_t s, SplitK sk) {
 
 }  // namespace
 
+#ifdef VG_DBG_STAMPS
+extern "C" int vg_debug_stamps(unsigned long long* host_out, int n) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(vg_dbg_stamps), (size_t)n * 8);
+}
+#endif
+
 extern "C" int vg_gather_gemm_nparts(const vg_gg_desc* d, int dtype) {
     int rc = validate(d, dtype);
     if (rc) return rc;

@@ -60,6 +60,15 @@ constexpr int gp_min_waves(int WM, int BN, int NR_) {
 //         History: with a 128-register cap (two workgroups per CU) it spilled and lost 30 %; at one workgroup per CU
 //         with two taps per barrier it was on par; with four taps per barrier it wins where the launch has >= 384
 //         tiles (G3 fprop 742 -> 780, G4 dgrad 689 -> 750 TFLOP/s) and loses at 256 tiles (G2 fprop 835 -> 806).
+#ifdef VG_DBG_STAMPS     // diagnostic build only (tools/probes/clock_probe.py): shader-clock / 100 MHz stamps of workgroup phases
+__device__ unsigned long long vg_dbg_stamps[8192 * 8];
+#define VG_STAMP(slot) do { if (threadIdx.x == 0) { const unsigned w_ = (blockIdx.x + gridDim.x * blockIdx.z) & 8191u; \
+        vg_dbg_stamps[w_ * 8 + (slot) * 2] = __builtin_amdgcn_s_memtime(); \
+        vg_dbg_stamps[w_ * 8 + (slot) * 2 + 1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define VG_STAMP(slot) do { } while (0)
+#endif
+
 template <int WM, int BN = GP_BN, int NR_ = 0>       // NR_: patch DMA rounds (0 = by tile shape); 3 where the patch has <= 192 pixels
 __global__ __launch_bounds__(128 * WM, gp_min_waves(WM, BN, NR_)) void ggp_kernel(const vg_gg_desc d, const PatchGeo g) {
     // BN = 128: wave tile 64 x 64; BN = 64 (layers with <= 64 output channels): wave tile 64 x 32; BN = 32: 64 x 16
@@ -91,6 +100,7 @@ __global__ __launch_bounds__(128 * WM, gp_min_waves(WM, BN, NR_)) void ggp_kerne
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int wm = wave / WN, wn = wave % WN;
     const int phase = blockIdx.z;
+    VG_STAMP(0);
     int bx, by;
     {
         const int n_tiles = (d.N + BN - 1) / BN;
@@ -241,14 +251,28 @@ __global__ __launch_bounds__(128 * WM, gp_min_waves(WM, BN, NR_)) void ggp_kerne
         u32x4 fa[TM], fb[TN];
         auto ld_a = [&](int i) {
             const int pp = ppbase[i] + tapoff;
+#ifdef VG_ABL_NO_FRAG           // timing-only: no LDS fragment reads (the matrix pipe runs on register garbage)
+            fa[i] = u32x4{(uint32_t)pp, (uint32_t)k, (uint32_t)lane, 0x3f803f80u};
+            (void)sa;
+#else
             fa[i] = *reinterpret_cast<const u32x4*>(sa + pp * 64 + ((fg ^ ((pp >> 1) & 3)) << 4));
+#endif
         };
         auto ld_b = [&](int j) {
             const int r = wn * WNC + j * 16 + fr;
+#ifdef VG_ABL_NO_FRAG
+            fb[j] = u32x4{(uint32_t)r, (uint32_t)bb, (uint32_t)lane, 0x3f803f80u};
+            (void)sb;
+#else
             fb[j] = *reinterpret_cast<const u32x4*>(sb + r * 64 + ((fg ^ ((-(r >> 2)) & 3)) << 4));
+#endif
         };
+#ifdef VG_ABL_NO_MFMA           // timing-only: fragment reads stay, the MFMAs go
+#define GP_MFMA(i, j) asm volatile("" ::"v"(fa[i]), "v"(fb[j]))
+#else
 #define GP_MFMA(i, j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]), \
                                                                   __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0)
+#endif
         if constexpr (TN == 4) {
             ld_a(0); ld_b(0); ld_b(1); ld_a(1); ld_b(2); ld_a(2); ld_b(3); ld_a(3);
             // MFMAs in the order their fragments arrive (fa0 fb0 | fb1 | fa1 | fb2 | fa2 | fb3 | fa3) ...
@@ -294,6 +318,7 @@ __global__ __launch_bounds__(128 * WM, gp_min_waves(WM, BN, NR_)) void ggp_kerne
     issue_patch_round(0, 2);
     if constexpr (NR == 4) issue_patch_round(0, 3);
     patch_advance();
+    VG_STAMP(1);
     if constexpr (TPS >= 2) {
         // ---- TPS taps per barrier, two weight slots: everything issued during a stage is drained at the next ----
         constexpr int SPC = 4 / TPS;                            // stages per chunk
@@ -305,8 +330,14 @@ __global__ __launch_bounds__(128 * WM, gp_min_waves(WM, BN, NR_)) void ggp_kerne
             const bool more_p = j + 1 < J;
 #pragma unroll
             for (int h = 0; h < SPC; ++h, ++s) {
+#if defined(VG_ABL_DMA_FREE)          // timing-only: stages issued back to back (the counter's 63-deep limit is the only brake)
+#elif defined(VG_ABL_DMA_AHEAD)       // timing-only: the newest VG_ABL_DMA_AHEAD DMA instructions may stay in flight (racy)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VG_ABL_DMA_AHEAD) : "memory");
+                __builtin_amdgcn_s_barrier();
+#else
                 VG_WAITCNT_VM(0);
                 __builtin_amdgcn_s_barrier();
+#endif
                 if (more_p) {
 #pragma unroll
                     for (int r = 0; r < NR; ++r)
@@ -346,6 +377,7 @@ __global__ __launch_bounds__(128 * WM, gp_min_waves(WM, BN, NR_)) void ggp_kerne
     }
     }
 
+    VG_STAMP(2);
     // ---------------- epilogue (as gg_kernel<bf16, 128, 128>) ----------------
 #ifdef VG_ABL_EPI_LGKM            // timing-only: workgroup barriers that do not wait for outstanding global stores
 #define GP_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
@@ -497,6 +529,7 @@ __global__ __launch_bounds__(128 * WM, gp_min_waves(WM, BN, NR_)) void ggp_kerne
 #endif
         }
     }
+    VG_STAMP(3);
 }
 
 #undef GP_SYNC

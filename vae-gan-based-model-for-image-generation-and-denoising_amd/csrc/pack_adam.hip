@@ -206,6 +206,26 @@ __global__ void adam_prep_kernel(float* state, double lr, double beta1, double b
     }
 }
 
+// The iteration's prologue in ONE single-thread launch: the noise generator's iteration counter (vg_rng_advance) and the
+// step counters / bias corrections of up to VG_PROLOGUE_MAX optimizers (what adam_prep_kernel does per optimizer).
+struct PrologueArgs {
+    unsigned long long* rng;
+    float* state[VG_PROLOGUE_MAX];
+    double lr[VG_PROLOGUE_MAX], beta1[VG_PROLOGUE_MAX], beta2[VG_PROLOGUE_MAX];
+    int n;
+};
+__global__ void step_prologue_kernel(const PrologueArgs a) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (a.rng != nullptr) a.rng[1] += 1ull;
+    for (int i = 0; i < a.n; ++i) {
+        float* state = a.state[i];
+        const double t = (double)state[0] + 1.0;
+        state[0] = (float)t;
+        state[1] = (float)(a.lr[i] / (1.0 - pow(a.beta1[i], t)));
+        state[2] = (float)sqrt(1.0 - pow(a.beta2[i], t));
+    }
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n4,
                                                    int64_t n, float w1, float beta2, float w2, float eps,
@@ -282,9 +302,11 @@ extern "C" int vg_adam_step(float* p, const float* g, float* m, float* v, int64_
     VG_CHECK_ARG(p && g && m && v && state && n > 0, VG_EINVAL);
     VG_CHECK_ARG(vg_aligned16(p) && vg_aligned16(g) && vg_aligned16(m) && vg_aligned16(v), VG_EALIGN);
     hipStream_t s = vg_stream(stream);
-    hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(64), 0, s, state, lr, beta1, beta2);
-    int rc = VG_LAUNCH_RC();
-    if (rc) return rc;
+    if (lr >= 0.0) {                                           // lr < 0: the iteration's vg_step_prologue has prepared `state`
+        hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(64), 0, s, state, lr, beta1, beta2);
+        int rc = VG_LAUNCH_RC();
+        if (rc) return rc;
+    }
     const int64_t n4 = n / 4;
     int blocks = (int)((n4 + 255) / 256);
     if (blocks < 1) blocks = 1;
@@ -295,5 +317,19 @@ extern "C" int vg_adam_step(float* p, const float* g, float* m, float* v, int64_
     const float w2 = (float)(1.0 - beta2);
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, p, g, m, v, n4, n, w1, (float)beta2, w2, (float)eps, grad_scale,
                        state);
+    return VG_LAUNCH_RC();
+}
+
+extern "C" int vg_step_prologue(uint64_t* rng, float* const* states, const double* lr, const double* beta1,
+                                const double* beta2, int n, void* stream) {
+    VG_CHECK_ARG(n >= 0 && n <= VG_PROLOGUE_MAX && (n == 0 || (states && lr && beta1 && beta2)) && (rng || n > 0), VG_EINVAL);
+    PrologueArgs a{};
+    a.rng = (unsigned long long*)rng;
+    a.n = n;
+    for (int i = 0; i < n; ++i) {
+        VG_CHECK_ARG(states[i] != nullptr && lr[i] >= 0.0, VG_EINVAL);
+        a.state[i] = states[i]; a.lr[i] = lr[i]; a.beta1[i] = beta1[i]; a.beta2[i] = beta2[i];
+    }
+    hipLaunchKernelGGL(step_prologue_kernel, dim3(1), dim3(1), 0, vg_stream(stream), a);
     return VG_LAUNCH_RC();
 }

@@ -4,6 +4,7 @@ Each function takes torch CUDA tensors (used only as device-memory handles), fil
 descriptor struct, and launches on torch's current HIP stream.  No computation happens in
 Python/ATen here.  All functions raise RuntimeError when the library rejects the arguments.
 """
+import os
 from ctypes import byref, c_int
 
 import torch
@@ -820,6 +821,19 @@ def axpy(a, b, alpha, out=None):
     out = out if out is not None else torch.empty_like(a)
     L.check(L.load().vg_axpy(a.data_ptr(), b.data_ptr(), alpha, out.data_ptr(), a.numel(), L.stream_ptr()), "vg_axpy")
     return out
+
+
+def step_prologue(noise, optimizers) -> None:
+    """Top of an iteration, one single-thread launch: noise.advance() (noise may be None) and the step counters / bias
+    corrections of `optimizers` (optim.Adam, at most 4) -- their step(prepared=True) then launches the update alone."""
+    import ctypes
+    n = len(optimizers)
+    states = (ctypes.c_void_p * max(n, 1))(*[o.state_dev.data_ptr() for o in optimizers])
+    lr = (ctypes.c_double * max(n, 1))(*[o.lr for o in optimizers])
+    b1 = (ctypes.c_double * max(n, 1))(*[o.betas[0] for o in optimizers])
+    b2 = (ctypes.c_double * max(n, 1))(*[o.betas[1] for o in optimizers])
+    L.check(L.load().vg_step_prologue(noise.state.data_ptr() if noise is not None else None, states, lr, b1, b2, n,
+                                      L.stream_ptr()), "vg_step_prologue")
 
 
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, grad_scale, state):

@@ -98,7 +98,9 @@ class Adam:
         for p in self.params:
             p._vg_fresh = True
 
-    def step(self, closure=None):
+    def step(self, closure=None, prepared: bool = False):
+        """prepared=True: this iteration's ops.step_prologue() has already advanced the step counter and the bias
+        corrections of this optimizer on the device; only the update kernel is launched."""
         if closure is not None:
             raise NotImplementedError("closure is not supported")
         for p, o in zip(self.params, self.offsets):
@@ -112,8 +114,8 @@ class Adam:
                     else:
                         view.copy_(g)
                     p.grad = view
-        ops.adam_step(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0], self.betas[1],
-                      self.eps, self.grad_scale, self.state_dev)
+        ops.adam_step(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, -1.0 if prepared else self.lr, self.betas[0],
+                      self.betas[1], self.eps, self.grad_scale, self.state_dev)
         self.steps += 1
         bump_weights_epoch(self.params)
 

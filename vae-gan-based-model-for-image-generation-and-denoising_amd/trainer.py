@@ -51,6 +51,9 @@ class VAEGANTrainer:
         # BCE + its gradient + the sigmoid / head backward as ONE launch per Discriminator pass (ops.head_backward;
         # bit-identical to the three separate launches, which False selects)
         self.fuse_head_backward = True
+        # noise counter + the three optimizers' step counters / bias corrections in ONE launch at the top of the iteration
+        # (ops.step_prologue) instead of one per optimizer step; False: every step() prepares itself
+        self.fuse_step_prologue = os.environ.get("VG_STEP_PROLOGUE", "1") != "0"
         self.reducer = reducer
         # sync_bn: BatchNorm statistics over the global batch of all ranks (ddp.py) -- an N-rank step then equals
         # the reference's single-process step on the concatenated batch.  Off: per-replica statistics.
@@ -97,7 +100,8 @@ class VAEGANTrainer:
         opts = tuple((o.lr, o.betas, o.eps, o.grad_scale, o.flat_p.data_ptr()) for o in (self.opt_E, self.opt_G, self.opt_D))
         return (tuple(real.shape), float(self.alpha_kl * min(1.0, epoch / 50)), inject, self.E.training, self.G.training,
                 self.D.training, self.alpha_adv, self.sigma, self.real_label, self.fake_label, self.d_iters,
-                self.elide_dead_grads, self.group_d_passes, self.fuse_head_backward, id(self.reducer), self.sync_bn, opts,
+                self.elide_dead_grads, self.group_d_passes, self.fuse_head_backward, self.fuse_step_prologue,
+                id(self.reducer), self.sync_bn, opts,
                 None if self.noise is None or inject else self.noise.state.data_ptr())
 
     # ---- data-parallel gradient hand-off (ddp.GradReducer) -------------------------------------------------------
@@ -161,14 +165,21 @@ class VAEGANTrainer:
         B, dev = real.shape[0], real.device
         L = self.latent
         real = real.contiguous()
+        noise = None
         if eps_z is None or eps_real is None or eps_recon is None:
             # the three randn_like draws (:77, :91, :92) are generated inside the kernels that consume them
-            # (Philox keyed by torch's device seed; vg_rng_advance bumps the iteration counter, also under replay)
+            # (Philox keyed by torch's device seed; the iteration counter is bumped on the device, also under replay)
             noise = self._noise_stream(dev)
-            noise.advance()
             eps_z = noise.draw(0) if eps_z is None else eps_z
             eps_real = noise.draw(1) if eps_real is None else eps_real
             eps_recon = noise.draw(2) if eps_recon is None else eps_recon
+        # one single-thread launch for everything that only counts: the noise iteration and the step counters / bias
+        # corrections of the three Adam steps below (the Discriminator's second update prepares itself)
+        prep = self.fuse_step_prologue and self.d_iters >= 1
+        if prep:
+            ops.step_prologue(noise, [self.opt_D, self.opt_G, self.opt_E])
+        elif noise is not None:
+            noise.advance()
         # slots 0..4 are written (not accumulated) below when d_iters >= 2; with d_iters = 1 slot 4 (d_loss_2) is never
         # written and with d_iters > 2 it holds the LAST iteration's loss -- zeroed so that it reads 0, not stale memory
         losses = ops.zeros_f32(8, dev)
@@ -220,7 +231,7 @@ class VAEGANTrainer:
                 D._engine.backward(c_real, dp_real, False, sink)
                 D._engine.backward(c_fake, dp_fake, False, sink, on_grads=self._grad_hook(self.opt_D, D))   # the accumulating pass
             self._finish_reduce(self.opt_D, D)            # D's buckets overlap the rest of its own backward
-            self.opt_D.step()
+            self.opt_D.step(prepared=prep and it == 0)
 
         # ---- Generator + VAE loss (:110-117) ----
         p_adv, c_adv = D.engine_forward(recon_noisy, B)
@@ -243,8 +254,8 @@ class VAEGANTrainer:
         dmulv = ops.reparam_kl_backward(mulv, lvc, eps_z, dz, kl_w / B, L, dt)
         E._engine.backward(ctxE, dmulv.view(B, 1, 1, -1), False, sink, on_grads=self._grad_hook(self.opt_E, E))
         self._finish_reduce(self.opt_E, E, also_wait=(self.opt_G,))
-        self.opt_E.step()
-        self.opt_G.step()
+        self.opt_E.step(prepared=prep)
+        self.opt_G.step(prepared=prep)
         self.losses = losses
         return losses
 
