@@ -570,6 +570,42 @@ def test_patch_gather_gemm_equals_reference_and_gather_path(ops, vg_switch, kind
     torch.testing.assert_close(outs[variant][1], outs["gather"][1], rtol=1e-5, atol=1e-3)
 
 
+@pytest.mark.parametrize("kind,B,H,Cin,Cout", [("convT", 8, 16, 32, 16), ("convT", 1, 128, 32, 16), ("conv_dgrad", 8, 32, 16, 32),
+                                               ("convT", 2, 64, 32, 12), ("conv_dgrad", 2, 256, 16, 32)])
+def test_patch_gather_gemm_16_columns_single_chunk(ops, vg_switch, kind, B, H, Cin, Cout):
+    """The 16-output-channel patch form of the S = 256 stacks (ConvTranspose2d(32 -> 16) forward, the data gradient of
+    Conv2d(16 -> 32); gan_code.py:21-49, :61-84 at img_size 256): K = 4 taps x 32 channels in ONE chunk, 256 x 16 tiles on four
+    waves, one patch buffer -- against torch fp64 and against the generic 256 x 16 gather tile, BatchNorm partial sums included;
+    64- and 128-wide grids (a two-row tile of a 128-wide grid is a 387-pixel patch), 12 real columns."""
+    dtype = G.BF16
+    g = torch.Generator().manual_seed(H * 5 + Cin)
+    if kind == "convT":
+        x = _q(torch.randn(B, Cin, H, H, generator=g), dtype)
+        w = torch.randn(Cin, Cout, 4, 4, generator=g) * 0.1
+        ref = F.conv_transpose2d(x, _q(w, dtype), None, stride=2, padding=1)
+        gg, pk = G.convT_fprop(B, H, H, Cin, Cout, 4, 2, 1, dtype)
+        nout = Cout
+    else:
+        x = _q(torch.randn(B, Cout, H // 2, H // 2, generator=g), dtype)
+        w = torch.randn(Cout, Cin, 4, 4, generator=g) * 0.1
+        ref = torch.nn.grad.conv2d_input((B, Cin, H, H), _q(w, dtype), x, stride=2, padding=1)
+        gg, pk = G.conv_dgrad(B, H, H, Cin, Cout, 4, 2, 1, dtype)
+        nout = Cin
+    assert gg.N <= 16 and gg.Kp == 128 and gg.nphase == 4
+    Wp = ops.pack_weights(pk, w.to(DEV), dtype)
+    X = _dev(to_nhwc(x, gg.IC), dtype, ops)
+    outs = {}
+    for mode in ("0", "1"):
+        vg_switch("VG_GG_PATCH16", mode)
+        Y, st, nparts = ops.gather_gemm(gg, X, Wp, dtype, want_stats=True)
+        assert nparts == gg.nphase * (gg.B * gg.GH * gg.GW // 256)
+        assert (Y[..., nout:] == 0).all()
+        outs[mode] = (from_nhwc(Y.double().cpu(), nout), st[: nparts * 2 * nout].view(nparts, 2, nout).double().sum(0).cpu())
+    close(outs["1"][0], ref, dtype)
+    close(outs["1"][0], outs["0"][0], dtype)
+    torch.testing.assert_close(outs["1"][1], outs["0"][1], rtol=1e-5, atol=1e-3)
+
+
 @pytest.mark.parametrize("kind,B,H,Cin,Cout", [("conv", 8, 16, 64, 128), ("convT", 8, 8, 128, 64), ("convT", 8, 1, 100, 1024),
                                                ("conv", 3, 16, 32, 64)])
 def test_workgroup_order_switches_do_not_change_results(ops, vg_switch, kind, B, H, Cin, Cout):
