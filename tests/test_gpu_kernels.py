@@ -554,6 +554,7 @@ def test_patch_gather_gemm_equals_reference_and_gather_path(ops, vg_switch, kind
     Wp = ops.pack_weights(pk, w.to(DEV), dtype)
     X = _dev(to_nhwc(x, gg.IC), dtype, ops)
     vg_switch("VG_TILE_MIN_WGS", "1")       # small problems still take the 128 x 128 tile
+    vg_switch("VG_GG_PHASE4", "0")          # (the <= 32-column transposed cases would go to conv_phase4.hpp: its own test below)
     outs = {}
     for mode in ("gather", variant):
         vg_switch("VG_GG_PATCH", "0" if mode == "gather" else "1")
@@ -570,13 +571,20 @@ def test_patch_gather_gemm_equals_reference_and_gather_path(ops, vg_switch, kind
     torch.testing.assert_close(outs[variant][1], outs["gather"][1], rtol=1e-5, atol=1e-3)
 
 
-@pytest.mark.parametrize("kind,B,H,Cin,Cout", [("convT", 8, 16, 32, 16), ("convT", 1, 128, 32, 16), ("conv_dgrad", 8, 32, 16, 32),
-                                               ("convT", 2, 64, 32, 12), ("conv_dgrad", 2, 256, 16, 32)])
-def test_patch_gather_gemm_16_columns_single_chunk(ops, vg_switch, kind, B, H, Cin, Cout):
-    """The 16-output-channel patch form of the S = 256 stacks (ConvTranspose2d(32 -> 16) forward, the data gradient of
-    Conv2d(16 -> 32); gan_code.py:21-49, :61-84 at img_size 256): K = 4 taps x 32 channels in ONE chunk, 256 x 16 tiles on four
-    waves, one patch buffer -- against torch fp64 and against the generic 256 x 16 gather tile, BatchNorm partial sums included;
-    64- and 128-wide grids (a two-row tile of a 128-wide grid is a 387-pixel patch), 12 real columns."""
+NARROW_CASES = [  # kind, B, H (input), Cin, Cout   (k4 s2 p1; <= 32 output channels of the 4-phase transposed form)
+    ("convT", 8, 16, 32, 16), ("convT", 1, 128, 32, 16), ("conv_dgrad", 8, 32, 16, 32), ("convT", 2, 64, 32, 12),
+    ("conv_dgrad", 2, 256, 16, 32),                                       # 16 columns, one chunk; 128-wide grid
+    ("convT", 2, 64, 64, 32), ("conv_dgrad", 4, 64, 32, 64), ("convT", 4, 32, 64, 32), ("convT", 16, 4, 96, 24),
+    ("convT", 16, 8, 32, 32), ("conv_dgrad", 1, 256, 32, 64),             # 32 columns, 1 - 3 chunks; multi-image tiles
+]
+
+
+@pytest.mark.parametrize("kind,B,H,Cin,Cout", NARROW_CASES)
+def test_narrow_transposed_layers_all_phases_per_workgroup(ops, vg_switch, kind, B, H, Cin, Cout):
+    """The narrow layers of the S >= 128 stacks (ConvTranspose2d(64 -> 32), (32 -> 16) forward, the data gradients of
+    Conv2d(16 -> 32), (32 -> 64); gan_code.py:21-49, :61-84 at img_size 128 / 256) on conv_phase4.hpp -- all four sub-pixel
+    phases of 256 grid pixels in one workgroup, union patch fetched once, whole output rows written: against torch fp64 and
+    against the generic per-tap gather tiles (one phase per workgroup), BatchNorm partial sums included; 4- to 128-wide grids (multi-image tiles, a two-row tile of a 128-wide grid), 12 and 24 real columns."""
     dtype = G.BF16
     g = torch.Generator().manual_seed(H * 5 + Cin)
     if kind == "convT":
@@ -591,19 +599,25 @@ def test_patch_gather_gemm_16_columns_single_chunk(ops, vg_switch, kind, B, H, C
         ref = torch.nn.grad.conv2d_input((B, Cin, H, H), _q(w, dtype), x, stride=2, padding=1)
         gg, pk = G.conv_dgrad(B, H, H, Cin, Cout, 4, 2, 1, dtype)
         nout = Cin
-    assert gg.N <= 16 and gg.Kp == 128 and gg.nphase == 4
+    assert gg.N <= 32 and gg.nphase == 4
+    M = gg.B * gg.GH * gg.GW
     Wp = ops.pack_weights(pk, w.to(DEV), dtype)
     X = _dev(to_nhwc(x, gg.IC), dtype, ops)
+    bias = torch.randn(nout, generator=g).to(DEV)
     outs = {}
-    for mode in ("0", "1"):
-        vg_switch("VG_GG_PATCH16", mode)
-        Y, st, nparts = ops.gather_gemm(gg, X, Wp, dtype, want_stats=True)
-        assert nparts == gg.nphase * (gg.B * gg.GH * gg.GW // 256)
+    vg_switch("VG_GG_PHASE4_MIN", "1")       # (by default only launches of >= 512 tiles come here)
+    for name, ph4 in (("generic", "0"), ("phase4", "1")):
+        vg_switch("VG_GG_PHASE4", ph4)
+        Y, st, nparts = ops.gather_gemm(gg, X, Wp, dtype, bias=bias, want_stats=True)
+        if name != "generic" or gg.N <= 16:
+            assert nparts == gg.nphase * (M // 256)
         assert (Y[..., nout:] == 0).all()
-        outs[mode] = (from_nhwc(Y.double().cpu(), nout), st[: nparts * 2 * nout].view(nparts, 2, nout).double().sum(0).cpu())
-    close(outs["1"][0], ref, dtype)
-    close(outs["1"][0], outs["0"][0], dtype)
-    torch.testing.assert_close(outs["1"][1], outs["0"][1], rtol=1e-5, atol=1e-3)
+        outs[name] = (from_nhwc(Y.double().cpu(), nout), st[: nparts * 2 * nout].view(nparts, 2, nout).double().sum(0).cpu())
+    refb = ref + bias.double().cpu().view(1, -1, 1, 1)
+    for name in outs:
+        close(outs[name][0], refb, dtype)
+        close(outs[name][0], outs["generic"][0], dtype)
+        torch.testing.assert_close(outs[name][1], outs["generic"][1], rtol=1e-5, atol=2e-3)
 
 
 @pytest.mark.parametrize("kind,B,H,Cin,Cout", [("conv", 8, 16, 64, 128), ("convT", 8, 8, 128, 64), ("convT", 8, 1, 100, 1024),

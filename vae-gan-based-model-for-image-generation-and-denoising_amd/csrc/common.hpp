@@ -141,7 +141,8 @@ struct VgSwitches {
     int gg_patch;          // VG_GG_PATCH          1: patch variant of the gather-GEMM
     int gg_patch64;        // VG_GG_PATCH64        1: its 64-column form
     int gg_patch32;        // VG_GG_PATCH32        1: its 32-column form
-    int gg_patch16;        // VG_GG_PATCH16        1: its 16-column form (single-chunk layers: K = 4 taps x 32 channels)
+    int gg_phase4;         // VG_GG_PHASE4         1: all four phases per workgroup for transposed layers with <= 32 output channels (conv_phase4.hpp)
+    int gg_phase4_min;     // VG_GG_PHASE4_MIN     512: ... where the launch has at least this many 256-pixel tiles
     int gg_patch_nr3;      // VG_GG_PATCH_NR3      1: 128 x 64 patch kernel with 3 patch rounds (4 workgroups per CU)
     int patch256_min;      // VG_PATCH256_MIN      256: least number of 256 x 128 tiles for the 8-wave patch kernel
     int patch256x64_min;   // VG_PATCH256X64_MIN   512: same for the 256 x 64 tile

@@ -670,6 +670,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 
 #include "conv_patch.hpp"
+#include "conv_phase4.hpp"
 #include "conv_narrowk.hpp"
 
 struct TileCfg { int bm, bn; };
@@ -686,12 +687,6 @@ inline int min_wgs() { return vg_sw().tile_min_wgs; }            // VG_TILE_MIN_
 // (a 256x128 tile -- wave tile 128x64, 152 VGPRs, one wave per SIMD -- was measured and loses on every layer)
 inline bool patch64() { return vg_sw().gg_patch64 != 0; }        // patch variant for the 128 x 64 tile (VG_GG_PATCH64)
 inline bool patch32() { return vg_sw().gg_patch32 != 0; }        // ... for 32-output-channel layers (S >= 128; VG_GG_PATCH32)
-inline bool patch16() { return vg_sw().gg_patch16 != 0; }        // ... for 16-output-channel single-chunk layers (S = 256; VG_GG_PATCH16)
-constexpr int GP16_PX = 448;                                     // 7 DMA rounds of 256 lanes
-inline bool patch16_ok(const vg_gg_desc* d, PatchGeo* pg) {
-    return d->N <= 16 && patch16() && use_patch() && use_dma() && d->zeros != nullptr && patch_geometry(d, 256, pg, GP16_PX) &&
-           pg->ncy * pg->ncx * pg->nct == 1;
-}
 inline bool patch_nr3() { return vg_sw().gg_patch_nr3 != 0; }    // 128 x 64 patch kernel with 3 patch rounds (40 KB LDS: 4 workgroups per CU)
 // 256 x 128 tiles where every CU gets at least one (step sweep: 128 / 192 / 256 / 384 -> 38.3 / 38.6 / 38.7 / 38.7k img/s)
 inline int patch256_min() { return vg_sw().patch256_min; }
@@ -709,6 +704,10 @@ inline TileCfg pick_tile(const vg_gg_desc* d, bool bf16 = false, bool fp8 = fals
         return {64, 64};
     }
     if (bf16 && narrowk_ok(d, VG_BF16)) return {NK_BM, N};       // 3-channel-input edge layers: ggn_kernel, all N per workgroup
+    if (bf16 && N <= 32 && use_dma()) {                           // narrow transposed layers: all four phases per workgroup
+        Q4Geo qg; int nr;
+        if (ggq_geometry(d, &qg, &nr)) return {256, N <= 16 ? 16 : 32};
+    }
     if (N <= 16) return {256, 16};
     if (N <= 32) return {128, 32};
     // 256 x 128 exists only as the patch kernel (bf16, LDS-DMA): 8 waves share every weight tile
@@ -876,12 +875,11 @@ extern "C" int vg_gather_gemm(const vg_gg_desc* d, int dtype, void* stream) {
     if (dtype == VG_F32) return dispatch<VG_F32>(d, t, vg_stream(stream), sk);
     if (dtype == VG_FP8) return dispatch<VG_FP8>(d, t, vg_stream(stream), sk);
     if (narrowk_ok(d, dtype)) return launch_narrowk(d, vg_stream(stream));
-    if (t.bm == 256 && t.bn == 16 && sk.ksplit <= 1 && patch16_ok(d, &pg)) {
-        const int m_tiles = (d->B * d->GH * d->GW) / 256;
-        dim3 grid(((m_tiles + 7) / 8) * 8, 1, d->nphase);
-        pg.n_major = 0;
-        vg_launch_timed(0, (ggp_kernel<4, 16, 7, 1>), grid, dim3(256), 0, vg_stream(stream), *d, pg);
-        return VG_LAUNCH_RC();
+    {
+        Q4Geo qg; int nr;
+        if (t.bm == 256 && t.bn <= 32 && use_dma() && sk.ksplit <= 1 && ggq_geometry(d, &qg, &nr))
+            return launch_phase4(d, qg, nr, vg_stream(stream));
+        if (t.bm == 256 && t.bn == 32) return VG_EINVAL;       // (switch flipped between planning and launch)
     }
     if ((t.bm == 128 || t.bm == 256) && (t.bn == GP_BN || (t.bn == 64 && patch64()) || (t.bn == 32 && d->N == 32 && patch32())) && sk.ksplit <= 1 &&
         use_patch() && use_dma() && d->zeros != nullptr && patch_geometry(d, t.bm, &pg)) {

@@ -47,7 +47,6 @@ constexpr int gp_min_waves(int WM, int BN, int NR_) {
     return WM == 4 ? 2 : 1;
 #endif
     if (GP_TPS != 2) return WM == 4 ? 2 : 1;
-    if (BN == 16) return 4;                     // 4-wave workgroups, 36 KB each: four per CU
     if (WM == 4) return BN <= 64 ? 4 : 2;
     return (2 * (NR_ ? NR_ : 4) * 4096 + 256 * BN <= 40960) ? 4 : 1;
 }
@@ -70,16 +69,10 @@ __device__ unsigned long long vg_dbg_stamps[8192 * 8];
 #define VG_STAMP(slot) do { } while (0)
 #endif
 
-// BN = 16 (WM = 4, NR_ = 7, PB = 1): the 16-output-channel layers of the S = 256 stacks (ConvTranspose2d(32 -> 16) forward,
-//         the data gradient of Conv2d(16 -> 32)): K = 4 taps x 32 channels is ONE chunk, so one patch buffer; 256 rows x 16
-//         columns on 4 waves (one per 64 rows, all 16 columns each), patch <= 448 pixels (two rows of a 128-wide grid:
-//         3 x 129 = 387), 36 KB: four workgroups per CU -- the layer is a stream (24 KB in, 8 KB out, 16 MFMAs per wave),
-//         bound by how many tiles a CU keeps in flight.  The generic 256 x 16 tile re-gathers the patch per tap: 2.7x the bytes.
-template <int WM, int BN = GP_BN, int NR_ = 0, int PB = 2>   // NR_: patch DMA rounds (0 = by tile shape); PB: patch buffers (1: single-chunk layers only)
-__global__ __launch_bounds__(64 * WM * (BN >= 32 ? 2 : 1), gp_min_waves(WM, BN, NR_)) void ggp_kernel(const vg_gg_desc d, const PatchGeo g) {
-    // BN = 128: wave tile 64 x 64; BN = 64 (layers with <= 64 output channels): wave tile 64 x 32; BN = 32, 16: 64 x 16
-    constexpr int WN = BN >= 32 ? 2 : 1;
-    constexpr int BM = 64 * WM, TM = 4, TN = BN / (16 * WN), NT = 64 * WM * WN, BST = BN * 64, WNC = BN / WN;
+template <int WM, int BN = GP_BN, int NR_ = 0>       // NR_: patch DMA rounds (0 = by tile shape); 3 where the patch has <= 192 pixels
+__global__ __launch_bounds__(128 * WM, gp_min_waves(WM, BN, NR_)) void ggp_kernel(const vg_gg_desc d, const PatchGeo g) {
+    // BN = 128: wave tile 64 x 64; BN = 64 (layers with <= 64 output channels): wave tile 64 x 32; BN = 32: 64 x 16
+    constexpr int BM = 64 * WM, WN = 2, TM = 4, TN = BN / 32, NT = 128 * WM, BST = BN * 64, WNC = BN / 2;
     constexpr int NR = NR_ ? NR_ : ((WM == 4 || GP_TPS != 2) ? 3 : 4);   /* WM == 4: 3 rounds of 512 lanes = 384 pixels */   // patch DMA rounds: 192 (3) or 256 (4) pixels per 128 rows
     constexpr int GP_PBUF = NR * NT * 16;           // NR rounds of NT lanes x 16 B
     constexpr int TPS = (WM == 4 && GP_TPS == 2) ? 4 : GP_TPS;   // 8 waves, one workgroup per CU: all 4 taps per barrier
@@ -88,8 +81,7 @@ __global__ __launch_bounds__(64 * WM * (BN >= 32 ? 2 : 1), gp_min_waves(WM, BN, 
     // 256 x 64: the 64-row weight tile needs only 256 of the 512 lanes -> waves 4-7 skip the weight DMA (legal here:
     // that variant never uses counted vmcnt waits, every stage drains with vmcnt(0))
     constexpr bool B_HALF = (BN * 4 < NT);
-    static_assert(BN == 128 || BN == 64 || BN == 32 || BN == 16, "supported shapes");
-    static_assert(PB == 2 || PB == 1, "one or two patch buffers");
+    static_assert(BN == 128 || BN == 64 || BN == 32, "supported shapes");
     static_assert(!B_HALF || TPS >= 2, "partial weight issue needs the drain-every-stage loop");
     // [patch buffers 2 x 12|24 KB][weight ring 3 x 8 KB][output-pixel table]
     // OVL (narrow tiles; 64 wide with 3 patch rounds and 32 wide: exactly 40 KB of stage buffers): the epilogue's output-pixel table lives in
@@ -100,9 +92,9 @@ __global__ __launch_bounds__(64 * WM * (BN >= 32 ? 2 : 1), gp_min_waves(WM, BN, 
 #else
     constexpr bool OVL = (TPS >= 2 && BN <= 64);
 #endif
-    __shared__ __attribute__((aligned(16))) unsigned char smem[PB * GP_PBUF + NB * BSTAGE + (OVL ? 0 : BM * 4)];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * GP_PBUF + NB * BSTAGE + (OVL ? 0 : BM * 4)];
     unsigned char* const pbuf = smem;
-    unsigned char* const bring = smem + PB * GP_PBUF;
+    unsigned char* const bring = smem + 2 * GP_PBUF;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -140,8 +132,7 @@ __global__ __launch_bounds__(64 * WM * (BN >= 32 ? 2 : 1), gp_min_waves(WM, BN, 
     const int J = ncls * g.nct;                                 // chunks
     const int S = J * 4;                                        // tap stages
     // stage s of the TPS >= 2 loop reads ring slot s & 1; J * (4 / TPS) stages -> the other slot is free from the last barrier on
-    int* const opix_tab = reinterpret_cast<int*>(OVL ? bring + ((J * (4 / TPS)) & 1) * BSTAGE : smem + PB * GP_PBUF + NB * BSTAGE);
-    if (PB == 1 && J != 1) return;                              // (host contract: the one-buffer form takes single-chunk layers only)
+    int* const opix_tab = reinterpret_cast<int*>(OVL ? bring + ((J * (4 / TPS)) & 1) * BSTAGE : smem + 2 * GP_PBUF + NB * BSTAGE);
 
     // ---- weight-tile DMA lanes: rows lrow, lrow + 64; source unit swizzled by the row (as gg_kernel) ----
     const int lrow = tid >> 2;
@@ -495,8 +486,8 @@ __global__ __launch_bounds__(64 * WM * (BN >= 32 ? 2 : 1), gp_min_waves(WM, BN, 
     }
 
     constexpr int CPITCH = BN * ESZ + 16;              // BM rows x 272 B = 34 | 68 KB <= the 48 | 72 KB of stage buffers
-    static_assert(BM * CPITCH <= PB * GP_PBUF + NB * BSTAGE, "C tile does not fit in LDS");
-    static_assert(!OVL || (BM * CPITCH <= PB * GP_PBUF && WM * BN * 8 <= PB * GP_PBUF), "C tile / statistics scratch would overwrite the overlaid pixel table");
+    static_assert(BM * CPITCH <= 2 * GP_PBUF + NB * BSTAGE, "C tile does not fit in LDS");
+    static_assert(!OVL || (BM * CPITCH <= 2 * GP_PBUF && WM * BN * 8 <= 2 * GP_PBUF), "C tile / statistics scratch would overwrite the overlaid pixel table");
     constexpr int SEGS = BN * ESZ / 16;
     unsigned char* Yb = reinterpret_cast<unsigned char*>(d.Y);
     const int oc_bytes = d.OC * ESZ;
@@ -544,7 +535,7 @@ __global__ __launch_bounds__(64 * WM * (BN >= 32 ? 2 : 1), gp_min_waves(WM, BN, 
 inline bool use_patch() { return vg_sw().gg_patch != 0; }      // VG_GG_PATCH (common.hpp: switches are read once at load)
 
 // Does the descriptor have one of the two patch forms, and does a bm-row tiling (128 or 256) line up?
-inline bool patch_geometry(const vg_gg_desc* d, int bm, PatchGeo* g, int max_px = 0) {   // max_px: patch pixels the variant's DMA rounds cover (0: by bm)
+inline bool patch_geometry(const vg_gg_desc* d, int bm, PatchGeo* g) {
     const bool transposed = d->TH == 2 && d->TW == 2 && d->SY == 1 && d->SX == 1 && (d->DY == 1 || d->DY == -1) &&
                             (d->DX == 1 || d->DX == -1);
     const bool direct2 = d->TH == 4 && d->TW == 4 && d->SY == 2 && d->SX == 2 && d->DY == 1 && d->DX == 1 &&
@@ -552,14 +543,14 @@ inline bool patch_geometry(const vg_gg_desc* d, int bm, PatchGeo* g, int max_px 
     if (!transposed && !direct2) return false;
     if (d->IC % 32 != 0 || d->Kp != d->TH * d->TW * d->IC) return false;
     const int GW = d->GW, GH = d->GH;
-    if (GW < 4 || GW > (max_px >= 387 ? 128 : 64) || (GW & (GW - 1)) || (GH & (GH - 1))) return false;
+    if (GW < 4 || GW > 64 || (GW & (GW - 1)) || (GH & (GH - 1))) return false;
     const int64_t M = (int64_t)d->B * GH * GW;
     if (M % bm != 0) return false;
     int R, IMGS;
     if (GH * GW >= bm) { IMGS = 1; R = bm / GW; if (R < 1 || GH % R) return false; }
     else { IMGS = bm / (GH * GW); R = GH; }
     g->R = R; g->IMGS = IMGS; g->PW = GW + 1; g->PIMG = (R + 1) * (GW + 1); g->NPP = IMGS * g->PIMG;
-    if (g->NPP > (max_px ? max_px : (bm == 256 ? 384 : (GP_TPS == 2 ? 256 : 192)))) return false;
+    if (g->NPP > (bm == 256 ? 384 : (GP_TPS == 2 ? 256 : 192))) return false;
     g->ncy = d->TH / 2; g->ncx = d->TW / 2; g->nct = d->IC / 32;
     return true;
 }

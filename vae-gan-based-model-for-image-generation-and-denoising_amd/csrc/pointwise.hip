@@ -928,7 +928,8 @@ void read_switches() {
     g_sw.gg_patch = env_int("VG_GG_PATCH", 1);
     g_sw.gg_patch64 = env_int("VG_GG_PATCH64", 1);
     g_sw.gg_patch32 = env_int("VG_GG_PATCH32", 1);
-    g_sw.gg_patch16 = env_int("VG_GG_PATCH16", 1);
+    g_sw.gg_phase4 = env_int("VG_GG_PHASE4", 1);
+    g_sw.gg_phase4_min = env_int("VG_GG_PHASE4_MIN", 512);
     g_sw.gg_patch_nr3 = env_int("VG_GG_PATCH_NR3", 1);
     g_sw.patch256_min = env_int("VG_PATCH256_MIN", 256);
     g_sw.patch256x64_min = env_int("VG_PATCH256X64_MIN", 512);
