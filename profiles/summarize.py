@@ -20,7 +20,7 @@ FAMILIES = {"gather_gemm": "gg_kernel", "wgrad": "wgrad_", "edge": "tnconv_kerne
 
 
 def fam_of(name):
-    if "gg_kernel" in name or "ggp_kernel" in name:      # gather-GEMM and its patch variant (conv_patch.hpp)
+    if "gg_kernel" in name or "ggp_kernel" in name or "ggq_kernel" in name:   # gather-GEMM, its patch variant (conv_patch.hpp), the 4-phase narrow form (conv_phase4.hpp)
         return "gather_gemm"
     if "tnconv_kernel" in name or "ggn_kernel" in name:  # edge layers (edge_conv.hip, conv_narrowk.hpp): HBM-bound
         return "edge"

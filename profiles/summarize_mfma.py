@@ -26,7 +26,7 @@ import sys
 
 
 def fam_of(name):
-    if "gg_kernel" in name or "ggp_kernel" in name:
+    if "gg_kernel" in name or "ggp_kernel" in name or "ggq_kernel" in name:
         return "gather_gemm"
     if "tnconv_kernel" in name or "ggn_kernel" in name:
         return "edge"

@@ -5,7 +5,7 @@ import csv, glob
 f = max(glob.glob("gpurun_out/gaps/*/*kernel_trace.csv"))
 rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(f))))
 # steady state: last 20 steps ~ find rng_advance kernels as step markers
-marks = [i for i, r in enumerate(rows) if "rng_advance" in r[2]]
+marks = [i for i, r in enumerate(rows) if "rng_advance" in r[2] or "step_prologue" in r[2]]
 marks = marks[-20:]
 steps = []
 for a, b in zip(marks[:-1], marks[1:]):

@@ -6,7 +6,7 @@ python3 - <<'PY'
 import csv, glob, re, collections
 f = max(glob.glob("gpurun_out/seq/*/*kernel_trace.csv"))
 rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Grid_Size_X", ""), r.get("Workgroup_Size_X", "")) for r in csv.DictReader(open(f))))
-marks = [i for i, r in enumerate(rows) if "rng_advance" in r[2]]
+marks = [i for i, r in enumerate(rows) if "rng_advance" in r[2] or "step_prologue" in r[2]]
 a, b = marks[-3], marks[-2]
 seg = rows[a:b]
 def short(n):
