@@ -146,8 +146,8 @@ struct VgSwitches {
     int gg_patch_nr3;      // VG_GG_PATCH_NR3      1: 128 x 64 patch kernel with 3 patch rounds (4 workgroups per CU)
     int patch256_min;      // VG_PATCH256_MIN      256: least number of 256 x 128 tiles for the 8-wave patch kernel
     int patch256x64_min;   // VG_PATCH256X64_MIN   512: same for the 256 x 64 tile
-    int splitk_max_tiles;  // VG_SPLITK_MAX_TILES  32: most output tiles for which the gather-GEMM splits K
-    int splitk_wgs;        // VG_SPLITK_WGS        256: workgroups a split-K launch aims at (tiles x splits)
+    int splitk_max_tiles;  // VG_SPLITK_MAX_TILES  128: most output tiles for which the gather-GEMM splits K
+    int splitk_wgs;        // VG_SPLITK_WGS        1024: workgroups a split-K launch aims at (tiles x splits; at most 64 splits)
     int gg_nmajor;         // VG_GG_NMAJOR         1: XCD-major over n tiles where the weights are the larger operand (2: always)
     int edge;              // VG_EDGE              1: narrow-K direct convolution for the 3-channel image layers
     int wg_reduce_t;       // VG_WG_REDUCE_T       1: streaming transpose-reduce of the weight-gradient slabs

@@ -762,7 +762,10 @@ inline SplitK plan_splitk(const vg_gg_desc* d, int dtype, TileCfg t) {
     const int tiles = gx * gy;
     const int max_tiles = vg_sw().splitk_max_tiles;
     if (tiles > max_tiles || nstages < 16) return r;
+    // aim at ~4 workgroups per CU, at most 64 splits (the Encoder's Linear layers -- 4 tiles, K = 50 176 at S = 256 -- are at
+    // their best there; more splits only add partial traffic), at least 4 stages per split
     int ks = vg_sw().splitk_wgs / tiles;
+    if (ks > 64) ks = 64;
     if (ks > nstages / 4) ks = nstages / 4;
     if (ks < 2) return r;
     r.sps = (nstages + ks - 1) / ks;
