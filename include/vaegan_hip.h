@@ -52,7 +52,8 @@ extern "C" {
                              4: vg_bn_finalize_act_forward, vg_bn_backward_finalize_apply;
                              7: vg_bce_pair_forward_backward;
                              8: vg_head_backward; round-3 prune -- the opt-in experiments of ABI 5 / 6 that measured slower (input prologue of
-                                vg_tn_desc / vg_ew_desc, vg_gg_desc.bnb_*) are gone from the descriptors; vg_reload_switches */
+                                vg_tn_desc / vg_ew_desc, vg_gg_desc.bnb_*) are gone from the descriptors; vg_reload_switches;
+                             9: vg_step_prologue, vg_adam_step(lr < 0) */
 int vg_abi_version(void);
 /* The library reads its optional kernel-selection switches (VG_* environment variables, DESIGN.md "Runtime switches")
  * ONCE, when it is loaded; nothing on a launch path calls getenv.  A process that changes one of them afterwards
