@@ -174,6 +174,11 @@ def test_c_abi_rejects_bad_arguments_on_host():
     w = L.WGDesc()
     assert lib.vg_wgrad_ws_bytes(ctypes.byref(w), 0) == -1
     assert lib.vg_adam_step(None, None, None, None, 0, 1e-3, 0.9, 0.999, 1e-8, 1.0, None, None) == -1
+    # the iteration prologue: nothing to do at all, too many optimizers, a NULL state
+    assert lib.vg_step_prologue(None, None, None, None, None, 0, None) == -1
+    assert lib.vg_step_prologue(None, None, None, None, None, 5, None) == -1
+    one = (ctypes.c_double * 1)(1e-3)
+    assert lib.vg_step_prologue(None, (ctypes.c_void_p * 1)(None), one, one, one, 1, None) == -1
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
