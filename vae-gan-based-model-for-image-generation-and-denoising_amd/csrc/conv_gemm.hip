@@ -755,6 +755,7 @@ inline SplitK plan_splitk(const vg_gg_desc* d, int dtype, TileCfg t) {
     const int M = d->B * d->GH * d->GW;
     const bool flat = d->nphase == 1 && d->OSY == 1 && d->OSX == 1 && d->GH == d->OH && d->GW == d->OW;
     if (!flat || d->stats != nullptr || d->act != VG_ACT_NONE || d->mask_x != nullptr || dtype == VG_FP8) return r;
+    if (t.bm == 256 && t.bn >= 32) return r;                    // the 256-row tiles exist as patch / 4-phase kernels only: no split form
     const int esz = dtype == VG_F32 ? 4 : 2;
     const int kch = dtype == VG_BF16 ? 2 : 1;
     const int nstages = ((d->Kp * esz) / 64 + kch - 1) / kch;
