@@ -618,6 +618,21 @@ def test_narrow_transposed_layers_all_phases_per_workgroup(ops, vg_switch, kind,
         close(outs[name][0], refb, dtype)
         close(outs[name][0], outs["generic"][0], dtype)
         torch.testing.assert_close(outs[name][1], outs["generic"][1], rtol=1e-5, atol=2e-3)
+    # the two fused epilogue forms of BatchNorm-less neighbours: LeakyReLU on the way out (forward), and the activation
+    # backward of the layer below as a mask on a data gradient (the Discriminator's first conv, gan_code.py:61-62)
+    mx = torch.randn(gg.B, gg.OH, gg.OW, gg.OC, generator=g).to(DEV).to(torch.bfloat16)
+    fused = {}
+    for name, ph4 in (("generic", "0"), ("phase4", "1")):
+        vg_switch("VG_GG_PHASE4", ph4)
+        Ya, _, _ = ops.gather_gemm(gg, X, Wp, dtype, bias=bias, act=(2, 0.2))
+        Ym, _, _ = ops.gather_gemm(gg, X, Wp, dtype, mask=(mx, 2, 0.2))
+        fused[name] = (Ya.float().cpu(), Ym.float().cpu())
+    ref_act = torch.nn.functional.leaky_relu(refb, 0.2)
+    close(from_nhwc(fused["phase4"][0].double(), nout), ref_act, dtype)
+    ref_mask = ref * torch.where(from_nhwc(mx.double().cpu(), nout) > 0, 1.0, 0.2)
+    close(from_nhwc(fused["phase4"][1].double(), nout), ref_mask, dtype)
+    for a_, b_ in zip(fused["phase4"], fused["generic"]):
+        torch.testing.assert_close(a_, b_, rtol=3e-2, atol=3e-2 * max(1.0, float(b_.abs().max())))
 
 
 @pytest.mark.parametrize("kind,B,H,Cin,Cout", [("conv", 8, 16, 64, 128), ("convT", 8, 8, 128, 64), ("convT", 8, 1, 100, 1024),
