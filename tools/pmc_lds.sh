@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS --output-format csv -d gpurun_out/pmc_lds -- python3 tools/layer_bench.py 64 128 bf16 3 "^G[2-4]|^D1" > gpurun_out/pmc_lds.log 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS --output-format csv -d gpurun_out/pmc_lds -- python3 tools/layer_bench.py ${PMC_LDS_ARGS:-64 128 bf16 3 "^G[2-4]|^D1"} > gpurun_out/pmc_lds.log 2>&1
 python3 - <<'PY'
 import csv, glob, collections, re
 f = max(glob.glob("gpurun_out/pmc_lds/*/*counter_collection.csv"))
