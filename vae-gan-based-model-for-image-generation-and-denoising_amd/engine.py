@@ -183,13 +183,16 @@ class StackEngine:
 
     def fp8_ok(self, i: int) -> bool:
         """Stage i's forward GEMM reads fp8 operands: a conv / convT whose packed bf16 operand has whole 64-element
-        K rows (then the fp8 operand is its elementwise cast) and >= 16 input channels; not the edge layers."""
+        K rows (then the fp8 operand is its elementwise cast) and >= 16 input channels; not the edge layers, and not the
+        layers with <= 32 output channels -- HBM-bound streams that gain nothing from a faster MFMA and have a bf16 kernel
+        of their own (csrc/conv_phase4.hpp: 2.8x the generic tile the fp8 launch would take)."""
         key = (i, "fp8")
         if key not in self._specs:
             st, ok = self.stages[i], False
             if self.fp8_fprop and st.kind in ("conv", "convT"):
                 gg, pk = self.spec(i, 1, "fprop")
-                ok = (not pk.tap_in_n and gg.IC % 16 == 0 and gg.Kp % 64 == 0 and self.tn(i, 1, "fprop") is None)
+                ok = (not pk.tap_in_n and gg.IC % 16 == 0 and gg.Kp % 64 == 0 and gg.N > 32 and
+                      self.tn(i, 1, "fprop") is None)
             self._specs[key] = ok
         return self._specs[key]
 
