@@ -48,12 +48,13 @@ extern "C" {
 #define VG_ACT_LRELU   2   /* nn.LeakyReLU(slope)    main_vae.py:25, gan_code.py:62-82 */
 #define VG_ACT_TANH    3   /* nn.Tanh()              gan_code.py:50 (vg_tnconv epilogue only) */
 
-#define VG_ABI_VERSION 9   /* 2: vg_pack_desc.tile_start, SyncBN / WGAN / data-path entry points; 3: in-kernel noise (vg_*_rng);
+#define VG_ABI_VERSION 10  /* 2: vg_pack_desc.tile_start, SyncBN / WGAN / data-path entry points; 3: in-kernel noise (vg_*_rng);
                              4: vg_bn_finalize_act_forward, vg_bn_backward_finalize_apply;
                              7: vg_bce_pair_forward_backward;
                              8: vg_head_backward; round-3 prune -- the opt-in experiments of ABI 5 / 6 that measured slower (input prologue of
                                 vg_tn_desc / vg_ew_desc, vg_gg_desc.bnb_*) are gone from the descriptors; vg_reload_switches;
-                             9: vg_step_prologue, vg_adam_step(lr < 0) */
+                             9: vg_step_prologue, vg_adam_step(lr < 0);
+                             10 (round 4): vg_adam_apply replaces the lr < 0 overload of vg_adam_step (which now rejects it) */
 int vg_abi_version(void);
 /* The library reads its optional kernel-selection switches (VG_* environment variables, DESIGN.md "Runtime switches")
  * ONCE, when it is loaded; nothing on a launch path calls getenv.  A process that changes one of them afterwards
@@ -443,8 +444,11 @@ int vg_adam_step(float* p, const float* g, float* m, float* v, int64_t n,
                  float* state /* [4] device */, void* stream);
 /* A training iteration that steps several optimizers (vaegan_code.py:105, :134-135) can prepare all of them -- step
  * count + 1, bias corrections -- together with the noise generator's iteration counter (rng may be NULL) in ONE
- * single-thread launch at its top; vg_adam_step called with lr < 0 then skips its own prepare launch and uses `state` as
- * it finds it.  Same double arithmetic as the per-optimizer prepare: bit-identical updates. */
+ * single-thread launch at its top; vg_adam_apply then launches the update alone and uses `state` as it finds it.  Same
+ * double arithmetic as the per-optimizer prepare: bit-identical updates.  (vg_adam_step rejects lr < 0: ABI 9 overloaded
+ * a negative learning rate as "prepared", which a caller's typo could trigger silently.) */
+int vg_adam_apply(float* p, const float* g, float* m, float* v, int64_t n, double beta1, double beta2, double eps,
+                  float grad_scale, const float* state /* prepared by vg_step_prologue */, void* stream);
 #define VG_PROLOGUE_MAX 4
 int vg_step_prologue(uint64_t* rng, float* const* states, const double* lr, const double* beta1, const double* beta2,
                      int n, void* stream);

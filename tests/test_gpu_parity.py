@@ -786,6 +786,56 @@ def test_dropin_autograd_path_matches_direct_trainer_and_oracle():
             assert rel(v, ref[n]) <= tol, f"step {step} {n}: drop-in {v} oracle {ref[n]}"
 
 
+def test_autograd_returns_real_gradients_where_adam_has_not_homed_them():
+    """writing parameter gradients in place and handing autograd None is only legal for parameters whose
+    .grad is vaegan_amd.Adam's slot.  (a) modules WITHOUT the engine's Adam: loss.backward() populates .grad through
+    AccumulateGrad (hooks fire) and torch.autograd.grad returns tensors; (b) with Adam homed and DIRECT_PARAM_GRADS=False
+    the returned gradients equal what the in-place path writes, bit for bit; (c) a frozen parameter gets no .grad."""
+    import importlib
+    nets_mod = importlib.import_module(V.Discriminator.__module__)
+    S, B = 64, 4
+    real = make_inputs(B, S, 8800)[0].to(DEV)
+
+    def build():
+        V.configure_seed(42)
+        d = V.Discriminator(img_size=S)
+        d.apply(V.weights_init)
+        return d.to(DEV).train()
+
+    # (a) no vaegan_amd.Adam at all: gradients must come back through autograd
+    d = build()
+    fired = []
+    w0 = next(d.parameters())
+    w0.register_hook(lambda g: fired.append(g.shape))
+    frozen = list(d.parameters())[-1]
+    frozen.requires_grad_(False)
+    d(real).sum().backward()
+    assert fired and frozen.grad is None
+    ga = {n: p.grad.clone() for n, p in d.named_parameters() if p.requires_grad}
+    assert all(g is not None and torch.isfinite(g).all() for g in ga.values())
+    params = [p for p in d.parameters() if p.requires_grad]
+    gl = torch.autograd.grad(d(real).sum(), params)
+    assert all(g is not None for g in gl)
+    # (b) homed by Adam: in place (default) == returned (DIRECT_PARAM_GRADS = False)
+    res = []
+    for direct in (True, False):
+        d = build()
+        opt = V.Adam(d.parameters(), lr=2e-4)
+        nets_mod.DIRECT_PARAM_GRADS = direct
+        try:
+            opt.zero_grad()
+            d(real).sum().backward()
+        finally:
+            nets_mod.DIRECT_PARAM_GRADS = True
+        res.append(opt.flat_g.clone())
+    assert torch.equal(res[0], res[1])
+    live = [n for n in ga if not n.endswith("conv.bias")]
+    for n, p in build().named_parameters():
+        if n in live:
+            o = dict(zip([k for k, _ in d.named_parameters()], opt.offsets))[n]
+            torch.testing.assert_close(res[0][o:o + p.numel()].view(p.shape), ga[n], rtol=1e-5, atol=1e-7)
+
+
 def _reference_shaped_step(encoder, decoder, discriminator, opt_E, opt_Dec, opt_Dis, bce, mse):
     """vaegan_code.py:65-135 as a function of (real_images, eps_z, eps_real, eps_recon; epoch) returning device tensors."""
     def step(real_images, ez, er, ec, epoch=60):
@@ -861,6 +911,39 @@ def test_graphed_reference_shaped_step_equals_the_eager_one_and_the_oracle(dtype
     for j, n in enumerate(V.LOSS_NAMES):
         tol = FIRST_STEP_TOL[n] if dtype == "fp32" else 3e-2
         assert rel(float(res[1][0][0, j]), ref[n]) <= tol, f"graphed drop-in {dtype} {n}: {float(res[1][0][0, j])} oracle {ref[n]}"
+
+
+def test_graphed_step_keeps_a_bounded_number_of_graphs_and_shares_equal_kl_weights():
+    """step(x, epoch=epoch) must not retain one graph (and one private memory pool) per epoch.  Ten distinct
+    epochs keep at most max_graphs entries; with scalar_key = the KL warm-up weight every epoch >= 50 replays ONE graph, and
+    that replay is bit-identical to the eager function."""
+    S, B = 64, 4
+    res = []
+    for mode in ("eager", "lru", "keyed"):
+        V.configure_seed(42)
+        nets = (V.Encoder([3, S, S], 100, dtype="bf16"), V.Generator(nz=100, img_size=S, dtype="bf16"),
+                V.Discriminator(img_size=S, dtype="bf16"))
+        nets[1].apply(V.weights_init), nets[2].apply(V.weights_init)
+        for m in nets:
+            m.to(DEV), m.train()
+        opts = tuple(V.Adam(m.parameters(), lr=2e-4) for m in nets)
+        step = _reference_shaped_step(*nets, *opts, torch.nn.BCELoss(), torch.nn.MSELoss(reduction="mean"))
+        if mode == "lru":
+            step = V.graphed(step, modules=nets, optimizers=opts, warmup=1)
+        elif mode == "keyed":
+            step = V.graphed(step, modules=nets, optimizers=opts, warmup=1, scalar_key=lambda epoch: min(1.0, epoch / 50))
+        losses = []
+        for epoch in range(50, 60):
+            for rep in range(2):
+                ins = [t.to(DEV) for t in make_inputs(B, S, 9100 + 2 * epoch + rep)]
+                losses.append(step(*ins, epoch=epoch).clone())
+        if mode == "lru":
+            assert len(step._graphs) <= 2 and len(step._seen) <= 16
+        if mode == "keyed":
+            assert len(step._graphs) == 1 and len(step._seen) == 1
+        torch.cuda.synchronize()
+        res.append(torch.stack(losses).cpu())
+    assert torch.equal(res[0], res[1]) and torch.equal(res[0], res[2])
 
 
 def test_modules_losses_mirror_torch():

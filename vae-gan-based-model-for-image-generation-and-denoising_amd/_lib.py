@@ -16,7 +16,7 @@ VG_F32, VG_BF16, VG_FP8 = 0, 1, 2
 VG_FP8_WSHIFT = 6
 VG_ACT_NONE, VG_ACT_RELU, VG_ACT_LRELU, VG_ACT_TANH = 0, 1, 2, 3
 VG_MAX_PHASE = 4
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _ERR = {-1: "VG_EINVAL (bad shape/size/flag)", -2: "VG_EALIGN (16-byte contract violated)",
         -3: "VG_ENOSUP (unsupported configuration)"}
@@ -136,6 +136,7 @@ SIGNATURES = {
     "vg_ssim": (c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _I, _P]),
     "vg_axpy": (c_int, [_P, _P, _F, _P, _L, _P]),
     "vg_adam_step": (c_int, [_P, _P, _P, _P, _L, _D, _D, _D, _D, _F, _P, _P]),
+    "vg_adam_apply": (c_int, [_P, _P, _P, _P, _L, _D, _D, _D, _F, _P, _P]),
     "vg_rng_advance": (c_int, [_P, _P]),
     "vg_step_prologue": (c_int, [_P, _P, _P, _P, _P, _I, _P]),
     "vg_randn": (c_int, [_P, _L, _P, _I, _P]),

@@ -297,16 +297,8 @@ extern "C" int vg_pack_weights_multi(const vg_pack_desc* descs_dev, int n, int64
     return VG_LAUNCH_RC();
 }
 
-extern "C" int vg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1,
-                            double beta2, double eps, float grad_scale, float* state, void* stream) {
-    VG_CHECK_ARG(p && g && m && v && state && n > 0, VG_EINVAL);
-    VG_CHECK_ARG(vg_aligned16(p) && vg_aligned16(g) && vg_aligned16(m) && vg_aligned16(v), VG_EALIGN);
-    hipStream_t s = vg_stream(stream);
-    if (lr >= 0.0) {                                           // lr < 0: the iteration's vg_step_prologue has prepared `state`
-        hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(64), 0, s, state, lr, beta1, beta2);
-        int rc = VG_LAUNCH_RC();
-        if (rc) return rc;
-    }
+static int adam_launch(float* p, const float* g, float* m, float* v, int64_t n, double beta1, double beta2, double eps,
+                       float grad_scale, float* state, hipStream_t s) {
     const int64_t n4 = n / 4;
     int blocks = (int)((n4 + 255) / 256);
     if (blocks < 1) blocks = 1;
@@ -318,6 +310,25 @@ extern "C" int vg_adam_step(float* p, const float* g, float* m, float* v, int64_
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, p, g, m, v, n4, n, w1, (float)beta2, w2, (float)eps, grad_scale,
                        state);
     return VG_LAUNCH_RC();
+}
+
+extern "C" int vg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1,
+                            double beta2, double eps, float grad_scale, float* state, void* stream) {
+    VG_CHECK_ARG(p && g && m && v && state && n > 0, VG_EINVAL);
+    VG_CHECK_ARG(lr >= 0.0, VG_EINVAL);                      // torch.optim.Adam: "Invalid learning rate"
+    VG_CHECK_ARG(vg_aligned16(p) && vg_aligned16(g) && vg_aligned16(m) && vg_aligned16(v), VG_EALIGN);
+    hipStream_t s = vg_stream(stream);
+    hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(64), 0, s, state, lr, beta1, beta2);
+    int rc = VG_LAUNCH_RC();
+    if (rc) return rc;
+    return adam_launch(p, g, m, v, n, beta1, beta2, eps, grad_scale, state, s);
+}
+
+extern "C" int vg_adam_apply(float* p, const float* g, float* m, float* v, int64_t n, double beta1, double beta2, double eps,
+                             float grad_scale, const float* state, void* stream) {
+    VG_CHECK_ARG(p && g && m && v && state && n > 0, VG_EINVAL);
+    VG_CHECK_ARG(vg_aligned16(p) && vg_aligned16(g) && vg_aligned16(m) && vg_aligned16(v), VG_EALIGN);
+    return adam_launch(p, g, m, v, n, beta1, beta2, eps, grad_scale, const_cast<float*>(state), vg_stream(stream));
 }
 
 extern "C" int vg_step_prologue(uint64_t* rng, float* const* states, const double* lr, const double* beta1,

@@ -93,7 +93,7 @@ int64_t wgrad_ws_bytes(at::IntArrayRef geom, int64_t dtype) {
 }
 
 void adam_step(at::Tensor& p, const at::Tensor& g, at::Tensor& m, at::Tensor& v, double lr, double beta1, double beta2,
-               double eps, double grad_scale, at::Tensor& state) {
+               double eps, double grad_scale, at::Tensor& state, bool prepared) {
     const at::Tensor* all[5] = {&p, &g, &m, &v, &state};
     for (const at::Tensor* t : all) {
         check_dev(*t, "adam_step");
@@ -101,6 +101,13 @@ void adam_step(at::Tensor& p, const at::Tensor& g, at::Tensor& m, at::Tensor& v,
     }
     TORCH_CHECK(g.numel() == p.numel() && m.numel() == p.numel() && v.numel() == p.numel() && state.numel() >= 3,
                 "vaegan::adam_step: buffer sizes differ");
+    if (prepared) {                                     // the iteration's vg_step_prologue has advanced `state` already
+        rc_check(vg_adam_apply(static_cast<float*>(p.data_ptr()), static_cast<const float*>(g.data_ptr()),
+                               static_cast<float*>(m.data_ptr()), static_cast<float*>(v.data_ptr()), p.numel(), beta1, beta2, eps,
+                               static_cast<float>(grad_scale), static_cast<const float*>(state.data_ptr()), cur_stream()),
+                 "adam_step");
+        return;
+    }
     rc_check(vg_adam_step(static_cast<float*>(p.data_ptr()), static_cast<const float*>(g.data_ptr()),
                           static_cast<float*>(m.data_ptr()), static_cast<float*>(v.data_ptr()), p.numel(), lr, beta1,
                           beta2, eps, static_cast<float>(grad_scale), static_cast<float*>(state.data_ptr()), cur_stream()),
@@ -134,7 +141,7 @@ TORCH_LIBRARY(vaegan, m) {
     m.def("wgrad(Tensor P, Tensor Q, Tensor(a!) dW, Tensor(b!) ws, Tensor zeros, int[] geom, int dtype) -> ()");
     m.def("wgrad_ws_bytes(int[] geom, int dtype) -> int");
     m.def("adam_step(Tensor(a!) p, Tensor g, Tensor(b!) m, Tensor(c!) v, float lr, float beta1, float beta2, float eps, "
-          "float grad_scale, Tensor(d!) state) -> ()");
+          "float grad_scale, Tensor(d!) state, bool prepared=False) -> ()");
     m.def("bn_act_forward(Tensor x, Tensor(a!) y, Tensor? scale, Tensor? shift, int rows, int C, int act, float slope, "
           "int groups, int gstride, int dtype) -> ()");
     m.def("pack_weights_multi(Tensor table, int n, int total_tiles, int dtype) -> ()");

@@ -67,18 +67,22 @@ def plan_buckets(offsets: Sequence[int], numels: Sequence[int], ready: Sequence[
             buckets.append((0, hi_b, ev_b))
         else:
             buckets.append((0, hi, ev))
+    if max_buckets > 0:
+        # Merge in BUFFER order (the buckets tile [0, total): neighbours in the sorted list are adjacent slices by
+        # construction), not in launch order: with a locally re-ordered layout two buckets that are neighbours in launch
+        # order need not touch, and a min..max span over the gap would overlap a third bucket (its gradients would be
+        # all-reduced twice).  For a layout whose events fall monotonically along the buffer both orders coincide.
+        def glue(a, b):                                   # a directly below b in the buffer -> one bucket (the later event)
+            if a[1] != b[0]:
+                raise RuntimeError(f"gradient buckets to merge are not adjacent slices: {a} / {b}")
+            return (a[0], b[1], min(a[2], b[2]))
+        buckets.sort(key=lambda b: b[0])
+        if len(buckets) > 1 and (buckets[0][1] - buckets[0][0]) * 4 < bucket_bytes:
+            buckets[0:2] = [glue(buckets[0], buckets[1])]    # a small tail (front of the buffer = end of the backward pass)
+        while len(buckets) > max_buckets:                    # merge from the END of the buffer = the first to be launched
+            buckets[-2:] = [glue(buckets[-2], buckets[-1])]
     # launch order = by event, descending; a later-closing bucket must never wait on an earlier event than it reports
     buckets.sort(key=lambda b: (-b[2], -b[0]))
-    if max_buckets > 0:
-        def glue(a, b):                                   # two buckets adjacent in the buffer -> one (the later event)
-            assert a[0] == b[1] or b[0] == a[1], "buckets to merge must be adjacent slices"
-            return (min(a[0], b[0]), max(a[1], b[1]), min(a[2], b[2]))
-        if len(buckets) > 1 and (buckets[-1][1] - buckets[-1][0]) * 4 < bucket_bytes:
-            tail = buckets.pop()
-            buckets.append(glue(buckets.pop(), tail))
-        while len(buckets) > max_buckets:
-            first = buckets.pop(0)
-            buckets[0] = glue(first, buckets[0])
     return buckets
 
 

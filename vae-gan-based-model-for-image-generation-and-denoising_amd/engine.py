@@ -109,18 +109,29 @@ class Stage:
 
 
 class GradSink:
-    """Where parameter gradients go.  direct=True: into param.grad (allocated or accumulated in
-    place -- trainer path); direct=False: fresh tensors collected for autograd to return."""
+    """Where parameter gradients go.  direct=True: into param.grad (allocated or accumulated in place -- trainer path);
+    direct=False: fresh tensors collected for autograd to return; direct="homed" (the autograd path's default): in place
+    for exactly those parameters whose .grad IS their slot of optim.Adam's flat gradient buffer and that are in `wanted`
+    (ids of the parameters autograd asked gradients for; None = all) -- every other parameter gets a fresh tensor that
+    is returned to autograd, so torch.autograd.grad(), AccumulateGrad hooks and foreign optimizers see real gradients."""
 
-    def __init__(self, direct: bool):
+    def __init__(self, direct, wanted=None):
         self.direct = direct
+        self.wanted = wanted
         self.out: Dict[int, torch.Tensor] = {}
+
+    def _in_place(self, param: torch.Tensor) -> bool:
+        if self.direct != "homed":
+            return bool(self.direct)
+        if self.wanted is not None and id(param) not in self.wanted:
+            return False
+        return param.grad is not None and getattr(param, "_vg_homed", None) == param.grad.data_ptr()
 
     def pair(self, pa: torch.Tensor, pb: torch.Tensor):
         """Gradient tensors of two parameters that one kernel writes as a fused [rows_a + rows_b, ...] block
         -> (grad_a, grad_b, accumulate).  direct: the optimizer's views (back to back when it homed the pair so);
         collected: one fresh allocation split in two."""
-        if not self.direct:
+        if not (self._in_place(pa) and self._in_place(pb)):
             t = torch.empty((pa.shape[0] + pb.shape[0],) + tuple(pa.shape[1:]), dtype=pa.dtype, device=pa.device)
             ga, gb = t[:pa.shape[0]], t[pa.shape[0]:]
             self.out[id(pa)], self.out[id(pb)] = ga, gb
@@ -133,7 +144,7 @@ class GradSink:
 
     def get(self, param: torch.Tensor):
         """-> (tensor to write, accumulate flag)"""
-        if not self.direct:
+        if not self._in_place(param):
             t = torch.empty_like(param)
             self.out[id(param)] = t
             return t, False
@@ -569,7 +580,10 @@ class StackEngine:
                     ops.memset_zero(gb)
                     # (remembered only for a slot of optim.Adam's flat gradient buffer, which nothing else writes; any
                     # other gradient tensor may be a recycled allocation and is zeroed every time)
-                    homed = sink.direct and getattr(st.conv.bias, "_vg_homed", None) == gb.data_ptr()
+                    # ... and only when the memset really ran: one that was merely RECORDED into a hipGraph capture (which
+                    # may still abort) proves nothing about the slot's contents
+                    homed = bool(sink.direct) and getattr(st.conv.bias, "_vg_homed", None) == gb.data_ptr() and \
+                        not torch.cuda.is_current_stream_capturing()
                     st.conv.bias._vg_zero_slot = gb.data_ptr() if homed else None
             else:
                 ops.bias_grad(dY, rows, OC, st.cout, gb, accb, dt)

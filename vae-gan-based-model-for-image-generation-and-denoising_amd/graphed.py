@@ -21,8 +21,19 @@ ragged last batch -- is captured as a graph of its own); every other argument is
 the capture key (``epoch`` changes the KL weight: a new value re-captures).  The first ``warmup`` calls of a signature
 run eagerly (they size workspaces and the allocator's pools), the next call captures and replays, later calls replay.
 Every call performs exactly one iteration.
+
+Memory: all graphs of one GraphedStep are captured into ONE shared memory pool and at most ``max_graphs`` (default 2:
+the full and the ragged last batch) are kept, least recently used first out -- ``step(x, epoch=epoch)`` over 200 epochs
+holds two graphs, not 200 private pools.  ``scalar_key`` maps the keyword scalars to what the captured launches really
+depend on, so that equal derived values share a graph: the reference's loop only uses ``epoch`` through the KL warm-up
+weight ``min(1, epoch / 50)`` (vaegan_code.py:117), hence
+
+    step = vaegan_amd.graphed(step, ..., scalar_key=lambda epoch: min(1.0, epoch / 50))
+
+captures once per warm-up value and never again from epoch 50 on.
 """
-from typing import Sequence
+from collections import OrderedDict
+from typing import Callable, Optional, Sequence
 
 import torch
 
@@ -46,10 +57,15 @@ def _flatten(out):
 
 
 class GraphedStep:
-    def __init__(self, fn, modules: Sequence = (), optimizers: Sequence = (), warmup: int = 2):
+    def __init__(self, fn, modules: Sequence = (), optimizers: Sequence = (), warmup: int = 2, max_graphs: int = 2,
+                 scalar_key: Optional[Callable] = None):
         self.fn, self.modules, self.optimizers, self.warmup = fn, tuple(modules), tuple(optimizers), max(1, int(warmup))
-        self._graphs = {}           # key -> (graph, static inputs, outputs, bn-tick deltas, step-count deltas)
-        self._seen = {}             # key -> eager calls so far
+        self.max_graphs = max(1, int(max_graphs))
+        self.scalar_key = scalar_key
+        # key -> (graph, static inputs, outputs, bn-tick deltas, step-count deltas); least recently used first
+        self._graphs = OrderedDict()
+        self._seen = OrderedDict()  # key -> eager calls so far (bounded like _graphs)
+        self._pool = None           # one memory pool for every capture of this step (created with the first one)
 
     def _engines(self):
         return [m._engine for m in self.modules if getattr(m, "_engine", None) is not None]
@@ -58,11 +74,13 @@ class GraphedStep:
         for t in tensors:
             if not isinstance(t, torch.Tensor) or not t.is_cuda:
                 raise RuntimeError("graphed step: positional arguments are device tensors ('cuda'); pass scalars by keyword")
-        key = (tuple((tuple(t.shape), t.dtype) for t in tensors), tuple(sorted(scalars.items())),
+        skey = tuple(sorted(scalars.items())) if self.scalar_key is None else self.scalar_key(**scalars)
+        key = (tuple((tuple(t.shape), t.dtype) for t in tensors), skey,
                tuple(m.training for m in self.modules),
                tuple((o.lr, o.betas, o.eps, o.grad_scale) for o in self.optimizers if hasattr(o, "grad_scale")))
         hit = self._graphs.get(key)
         if hit is not None:
+            self._graphs.move_to_end(key)
             graph, sin, out, dticks, dsteps = hit
             for s, t in zip(sin, tensors):
                 if s.data_ptr() != t.data_ptr():
@@ -73,7 +91,15 @@ class GraphedStep:
         n = self._seen.get(key, 0)
         if n < self.warmup:
             self._seen[key] = n + 1
+            self._seen.move_to_end(key)
+            while len(self._seen) > 8 * self.max_graphs:
+                self._seen.popitem(last=False)
             return self.fn(*tensors, **scalars)
+        # make room first: an evicted graph hands its share of the pool back before the new capture allocates
+        while len(self._graphs) >= self.max_graphs:
+            self._graphs.popitem(last=False)
+        if self._pool is None:
+            self._pool = torch.cuda.graph_pool_handle()
         # ---- capture ----
         sin = [t.clone() for t in tensors]
         engines = self._engines()
@@ -89,7 +115,7 @@ class GraphedStep:
             with no_gc_while_capturing(), torch.cuda.stream(cap):
                 # global capture mode (the default): the autograd engine runs the backward nodes on its own device thread,
                 # which launches into this stream -- their work is captured with the rest
-                graph.capture_begin()
+                graph.capture_begin(pool=self._pool)
                 try:
                     out = self.fn(*sin, **scalars)
                 finally:
@@ -124,8 +150,11 @@ class GraphedStep:
             o.steps += d
 
 
-def graphed(fn, modules: Sequence = (), optimizers: Sequence = (), warmup: int = 2) -> GraphedStep:
+def graphed(fn, modules: Sequence = (), optimizers: Sequence = (), warmup: int = 2, max_graphs: int = 2,
+            scalar_key: Optional[Callable] = None) -> GraphedStep:
     """Wrap a reference-shaped training step for hipGraph replay (see the module docstring).
     modules: the engine networks the step calls (their BatchNorm forward counters and packed operands are host-side
-    mirrors the replay keeps in step); optimizers: the vaegan_amd.Adam instances it steps."""
-    return GraphedStep(fn, modules, optimizers, warmup)
+    mirrors the replay keeps in step); optimizers: the vaegan_amd.Adam instances it steps; max_graphs: captured graphs
+    kept (least recently used evicted); scalar_key(**scalars) -> hashable: what of the keyword scalars the captured
+    launches depend on (default: the scalars themselves)."""
+    return GraphedStep(fn, modules, optimizers, warmup, max_graphs, scalar_key)

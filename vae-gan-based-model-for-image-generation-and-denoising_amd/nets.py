@@ -117,15 +117,18 @@ class _StackFn(torch.autograd.Function):
         net = ctx.net
         if ctx.saved is None:
             raise RuntimeError("backward called on a forward that ran under torch.no_grad()")
-        # Parameter gradients.  Default (DIRECT_PARAM_GRADS): the kernels write / accumulate straight into param.grad
-        # -- the optimizer's flat gradient buffer (optim.Adam), overwrite-after-zero_grad as in the direct trainer --
-        # and autograd is handed None for the parameters: no AccumulateGrad add kernel per parameter (91 small ATen
-        # launches per reference-shaped iteration).  torch.autograd.grad(...) callers, who want the gradients RETURNED,
-        # set nets.DIRECT_PARAM_GRADS = False.
-        need_p = any(ctx.needs_input_grad[2:])
-        sink = GradSink(direct=DIRECT_PARAM_GRADS)
+        # Parameter gradients.  Default (DIRECT_PARAM_GRADS): for a parameter whose .grad IS its slot of optim.Adam's flat
+        # gradient buffer (and that autograd wants a gradient for) the kernels write / accumulate straight into that slot
+        # -- overwrite-after-zero_grad as in the direct trainer -- and autograd is handed None for it: no AccumulateGrad
+        # add kernel per parameter (91 small ATen launches per reference-shaped iteration).  Every other parameter (no
+        # vaegan_amd.Adam, .grad replaced or None, torch.autograd.grad(...) with DIRECT_PARAM_GRADS = False) gets its
+        # gradient RETURNED, so AccumulateGrad hooks, torch DDP and foreign optimizers keep working.
+        params = net._engine.params()
+        wanted = {id(p) for p, need in zip(params, ctx.needs_input_grad[2:]) if need}
+        need_p = bool(wanted)
+        sink = GradSink(direct="homed" if DIRECT_PARAM_GRADS else False, wanted=wanted)
         dx = net._backward_impl(ctx.saved, douts, ctx.needs_input_grad[1], sink, param_grads=need_p)
-        grads = [None if DIRECT_PARAM_GRADS else sink.out.get(id(p)) for p in net._engine.params()]
+        grads = [sink.out.get(id(p)) if id(p) in wanted else None for p in params]
         ctx.saved = None
         return (None, dx, *grads)
 

@@ -836,10 +836,18 @@ def step_prologue(noise, optimizers) -> None:
                                       L.stream_ptr()), "vg_step_prologue")
 
 
-def adam_step(p, g, m, v, lr, beta1, beta2, eps, grad_scale, state):
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, grad_scale, state, prepared: bool = False):
+    """prepared=True: `state` (step count, bias corrections) was advanced by this iteration's step_prologue; only the
+    update kernel is launched (vg_adam_apply)."""
     _need_cuda(p, g, m, v, state)
+    if lr < 0:
+        raise ValueError(f"Invalid learning rate: {lr}")
     if BINDING == "torchops":
-        torch_ops().adam_step(p, g, m, v, lr, beta1, beta2, eps, grad_scale, state)
+        torch_ops().adam_step(p, g, m, v, lr, beta1, beta2, eps, grad_scale, state, bool(prepared))
+        return
+    if prepared:
+        L.check(L.load().vg_adam_apply(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), beta1, beta2, eps,
+                                       grad_scale, state.data_ptr(), L.stream_ptr()), "vg_adam_apply")
         return
     L.check(L.load().vg_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1,
                                   beta2, eps, grad_scale, state.data_ptr(), L.stream_ptr()), "vg_adam_step")

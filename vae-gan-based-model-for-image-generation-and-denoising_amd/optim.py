@@ -26,6 +26,8 @@ class Adam:
         if weight_decay != 0 or amsgrad:
             raise NotImplementedError("only the torch.optim.Adam defaults used by the reference are implemented "
                                       "(weight_decay=0, amsgrad=False)")
+        if lr < 0.0:
+            raise ValueError(f"Invalid learning rate: {lr}")                  # torch.optim.Adam's own check and wording
         self.params = [p for p in params]
         if not self.params:
             raise ValueError("optimizer got an empty parameter list")
@@ -114,8 +116,8 @@ class Adam:
                     else:
                         view.copy_(g)
                     p.grad = view
-        ops.adam_step(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, -1.0 if prepared else self.lr, self.betas[0],
-                      self.betas[1], self.eps, self.grad_scale, self.state_dev)
+        ops.adam_step(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0],
+                      self.betas[1], self.eps, self.grad_scale, self.state_dev, prepared=prepared)
         self.steps += 1
         bump_weights_epoch(self.params)
 

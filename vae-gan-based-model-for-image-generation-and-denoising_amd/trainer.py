@@ -159,6 +159,25 @@ class VAEGANTrainer:
     def train_step(self, real: torch.Tensor, epoch: int, eps_z: Optional[torch.Tensor] = None,
                    eps_real: Optional[torch.Tensor] = None, eps_recon: Optional[torch.Tensor] = None) -> torch.Tensor:
         """One iteration.  Returns a device tensor [recon_loss, kl_loss, g_loss_adv, d_loss_1, d_loss_2]."""
+        steps = [o.steps for o in (self.opt_E, self.opt_G, self.opt_D)]
+        try:
+            return self._train_step(real, epoch, eps_z, eps_real, eps_recon)
+        except BaseException:
+            # The step prologue advances the DEVICE step counters / bias corrections of all three optimizers at the top of
+            # the iteration, the host mirrors (opt.steps) move with the updates at its end.  An eager iteration that dies
+            # in between (OOM, a bad shape in a later pass) must not leave the two apart: a retried iteration would apply
+            # t + 2 and state_dict() would save a step count that disagrees with the bias correction in use.  (A capture
+            # executes nothing: train_step_graphed restores the host mirrors itself.)
+            if not torch.cuda.is_current_stream_capturing():
+                for o, st in zip((self.opt_E, self.opt_G, self.opt_D), steps):
+                    if o.steps == st:
+                        try:
+                            o.state_dev[0:1].fill_(float(st))
+                        except Exception:
+                            pass
+            raise
+
+    def _train_step(self, real, epoch, eps_z, eps_real, eps_recon) -> torch.Tensor:
         if not real.is_cuda:
             raise RuntimeError("train_step needs the batch on the MI355X ('cuda'); there is no CPU path")
         E, Gn, D, dt = self.E, self.G, self.D, self.dt
