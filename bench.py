@@ -37,7 +37,7 @@ PEAK = {"fp32": 157.3, "bf16": 2500.0, "fp8": 5000.0}          # dense MFMA TFLO
 def pmc_traffic(dtype):
     """(bytes per gather-GEMM launch, source file) from the newest committed PMC summary
     (profiles/rNN_<dtype>_pmc_traffic.json): measured offline by separate rocprofv3 --pmc passes, not by this run."""
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02", "r01"):
         f = os.path.join(ROOT, "profiles", f"{rnd}_{dtype}_pmc_traffic.json")
         try:
             return round(json.load(open(f))["families"]["gather_gemm"]["hbm_bytes_per_launch"]), os.path.relpath(f, ROOT)
@@ -50,7 +50,7 @@ def pmc_mfma_busy(dtype):
     """(MFMA-busy fraction of the gather-GEMM family, of the whole run, source file) from the newest committed
     rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE pass (profiles/rNN_<dtype>_mfma_busy.json, made by
     profiles/summarize_mfma.py): measured offline by that separate pass, not by this run."""
-    for rnd in ("r03",):
+    for rnd in ("r04", "r03"):
         f = os.path.join(ROOT, "profiles", f"{rnd}_{dtype}_mfma_busy.json")
         try:
             j = json.load(open(f))
@@ -154,15 +154,42 @@ def time_steps(fn, warm, steps):
     return (time.perf_counter() - t0) / steps
 
 
-def parity_path(V, S, B, dev, inputs, steps=10):
-    """The fp32 engine (exact-f32 MFMA; the path whose first-step losses are held to 1e-4 against the reference,
-    tests/test_gpu_parity.py) on the same workload, hipGraph replay."""
+def parity_path(V, S, B, dev, inputs, ops, steps=10):
+    """The fp32 engine (exact-f32 MFMA, v_mfma_f32_16x16x4_f32: the reference's own arithmetic; the path whose first-step
+    losses are held to 1e-4 against the reference, tests/test_gpu_parity.py) on the same workload, hipGraph replay -- with
+    its OWN roofline against the 157.3 TFLOP/s fp32-MFMA peak, timed like the bf16 one (HIP start/stop events around every
+    launch in an eager pass of the same steps right after the replayed ones)."""
     e, g, d = build_models(V, S, "fp32", dev)
     tr = V.VAEGANTrainer(e, g, d, *(V.Adam(m.parameters(), lr=2e-4) for m in (e, g, d)))
     tr.train()
     dt = time_steps(lambda: tr.train_step_graphed(inputs[0], 60, *inputs[1:]), 3, steps)
-    return {"dtype": "f32", "value": round(B / dt, 1), "unit": "images/sec", "ms_per_step": round(dt * 1e3, 3),
-            "steps": steps, "mode": "VAEGANTrainer.train_step_graphed, injected noise"}
+    out = {"dtype": "f32", "value": round(B / dt, 1), "unit": "images/sec", "ms_per_step": round(dt * 1e3, 3),
+           "steps": steps, "mode": "VAEGANTrainer.train_step_graphed, injected noise"}
+    timer = ops.KernelTimer()
+    ops.set_timer(timer)
+    n0 = ops.launch_count()
+    for _ in range(steps):
+        tr.train_step(inputs[0], 60, *inputs[1:])
+    torch.cuda.synchronize()
+    ops.set_timer(None)
+    out["launches_per_step"] = (ops.launch_count() - n0) // steps
+    fam = timer.summary()
+    gg, wg = fam.get("gather_gemm"), fam.get("wgrad")
+    if gg and gg["launches"]:
+        ach = gg["flops"] / (gg["ms"] * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "kernel": "gg_kernel<f32> (gather-GEMM on v_mfma_f32_16x16x4_f32: conv/convT/linear fprop + dgrad)",
+                           "achieved": round(ach, 2), "peak": PEAK["fp32"], "unit": "TFLOP/s", "frac": round(ach / PEAK["fp32"], 4),
+                           "traffic": None, "launches_per_step": gg["launches"] // steps,
+                           "avg_launch_us": round(gg["ms"] * 1e3 / gg["launches"], 2),
+                           "share_of_step": round(gg["ms"] / steps / (dt * 1e3), 3),
+                           "timed_in": "eager pass after the replayed steps: HIP start/stop events around every launch on its stream",
+                           "step_alg_tflops": round(ALG_GFLOP_PER_IMAGE.get(S, 0) * B / (dt * 1e3), 2)}
+        if wg and wg["launches"]:
+            awg = wg["flops"] / (wg["ms"] * 1e-3) / 1e12
+            out["roofline"]["wgrad"] = {"achieved": round(awg, 2), "frac": round(awg / PEAK["fp32"], 4),
+                                        "launches_per_step": wg["launches"] // steps,
+                                        "share_of_step": round(wg["ms"] / steps / (dt * 1e3), 3)}
+    return out
 
 
 def elided_path(V, S, B, dev, dtype, inputs, steps=20):
@@ -375,10 +402,14 @@ def main():
         # eager launches still takes part in these collectives (its timed-loop recording is simply replaced).
         timer = ops.KernelTimer() if rank == 0 else None
         ops.set_timer(timer)
+        n_launch0 = ops.launch_count()
         for _ in range(args.steps):
             tr.train_step(real, epoch, ez, er, ec)
         torch.cuda.synchronize()
         ops.set_timer(None)
+        launches_per_step = (ops.launch_count() - n_launch0) / args.steps
+    else:
+        launches_per_step = None
     if rank != 0:
         if multi:
             dist.destroy_process_group()
@@ -443,6 +474,9 @@ def main():
                                   f"batch {B}/GPU, global batch {B * world}", "img_size": S, "per_gpu_batch": B,
                       "global_batch": B * world, "parallelism": f"dp{world}", "epoch_kl_weight": 0.1,
                       "elide_dead_grads": bool(args.elide_dead_grads), "hip_graph": use_graph},
+           # kernel launches of libvaegan_hip.so per iteration (vg_launch_count over the eager pass that follows the timed
+           # region; the replayed graph holds the same launches).  Round 3: 193 by rocprofv3.
+           "kernel_launches_per_step": launches_per_step,
            "losses": {k: round(v, 5) for k, v in ld.items()},
            "roofline": roofline}
     if roofline_edge is not None:
@@ -471,7 +505,7 @@ def main():
     if world == 1 and not multi and not args.no_extra_paths:
         del tr, e, g, d, oE, oG, oD
         out["denoise_path"] = denoise_path(V, S, B, dev, args.dtype, resident)
-        out["parity_path"] = parity_path(V, S, B, dev, resident)
+        out["parity_path"] = parity_path(V, S, B, dev, resident, ops)
         out["elided_path"] = elided_path(V, S, B, dev, args.dtype, resident)
         out["dropin_path"] = dropin_path(V, S, B, dev, args.dtype, resident)
         try:                                    # the same loop with the hot ops bound through torch.ops.vaegan.*

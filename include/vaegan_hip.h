@@ -64,6 +64,9 @@ int vg_reload_switches(void);
  * launches carry a HIP start/stop event pair on their stream (hipExtLaunchKernelGGL); collect() synchronises,
  * sums the kernel times in ms, returns the launch count and resets the family.  Do not enable during capture. */
 int vg_timing_enable(int on);
+/* Kernel launches issued by this library since it was loaded (every hipLaunchKernelGGL / hipExtLaunchKernelGGL of csrc/;
+ * memsets and copies are runtime calls, not counted).  bench.py: launches per training iteration. */
+uint64_t vg_launch_count(void);
 int vg_timing_collect(int family, double* total_ms /* host */, int* launches /* host */);
 /* Which tile configuration the launcher would pick (for tests / bench reporting). */
 const char* vg_build_info(void);

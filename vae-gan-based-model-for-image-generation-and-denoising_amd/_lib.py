@@ -81,6 +81,7 @@ class PackDesc(Structure):
 _P, _F, _I, _L, _D = c_void_p, c_float, c_int, c_int64, c_double
 SIGNATURES = {
     "vg_abi_version": (c_int, []),
+    "vg_launch_count": (ctypes.c_uint64, []),
     "vg_reload_switches": (c_int, []),
     "vg_build_info": (c_char_p, []),
     "vg_timing_enable": (c_int, [_I]),

@@ -9,6 +9,18 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
 #define VG_CHECK_ARG(cond, code) do { if (!(cond)) return (code); } while (0)
+
+// Every kernel launch of the library is counted (vg_launch_count(), C ABI): bench.py reports kernel launches per training
+// iteration from it, live, next to the rocprofv3 trace that shows the same number.  hipLaunchKernelGGL is HIP's macro around
+// the triple-chevron launch; it is re-defined here with the counter in front.
+#include <atomic>
+std::atomic<uint64_t>& vg_launch_counter();
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernelName, numBlocks, numThreads, memPerBlock, streamId, ...)                       \
+    do {                                                                                                        \
+        vg_launch_counter().fetch_add(1, std::memory_order_relaxed);                                            \
+        kernelName<<<(numBlocks), (numThreads), (memPerBlock), (streamId)>>>(__VA_ARGS__);                      \
+    } while (0)
 #define VG_LAUNCH_RC() ((int)hipGetLastError())
 
 static inline hipStream_t vg_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
@@ -128,6 +140,7 @@ inline void vg_launch_timed(int family, K kernel, dim3 grid, dim3 block, size_t 
         e0 = get(); e1 = get();
         t.rec[family].push_back({e0, e1});
     }
+    vg_launch_counter().fetch_add(1, std::memory_order_relaxed);
     hipExtLaunchKernelGGL(kernel, grid, block, shm, s, e0, e1, 0, args...);
 }
 

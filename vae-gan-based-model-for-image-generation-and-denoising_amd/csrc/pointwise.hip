@@ -957,6 +957,13 @@ VgTiming& vg_timing() {
     return t;
 }
 
+std::atomic<uint64_t>& vg_launch_counter() {
+    static std::atomic<uint64_t> n{0};
+    return n;
+}
+
+extern "C" uint64_t vg_launch_count(void) { return vg_launch_counter().load(std::memory_order_relaxed); }
+
 extern "C" int vg_timing_enable(int on) {
     VgTiming& t = vg_timing();
     std::lock_guard<std::mutex> g(t.mu);

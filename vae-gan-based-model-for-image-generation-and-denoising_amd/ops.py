@@ -836,6 +836,11 @@ def step_prologue(noise, optimizers) -> None:
                                       L.stream_ptr()), "vg_step_prologue")
 
 
+def launch_count() -> int:
+    """Kernel launches libvaegan_hip.so has issued so far in this process (vg_launch_count)."""
+    return int(L.load().vg_launch_count())
+
+
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, grad_scale, state, prepared: bool = False):
     """prepared=True: `state` (step count, bias corrections) was advanced by this iteration's step_prologue; only the
     update kernel is launched (vg_adam_apply)."""
