@@ -432,6 +432,20 @@ int vg_memset_zero(void* p, int64_t nbytes, void* stream);
 /* bf16 -> OCP e4m3fn, elementwise: y[i] = fp8(x[i] * 2^shift).  The fp8 copies of activations (shift 0) and of the
  * packed bf16 GEMM operands (shift VG_FP8_WSHIFT) that VG_FP8 launches of vg_gather_gemm read.  n % 8 == 0. */
 int vg_cast_fp8(const void* x_bf16, void* y_fp8, int64_t n, int shift, void* stream);
+/* BatchNorm(+activation) backward in ONE launch (csrc/bn_onepass.hip; bf16, C a power of two in [8, 1024], tensors of up to
+ * 65 536 elements per CU): column sums, coefficients and dx = a*dz - b*xhat - c with the x / dy block of a workgroup held in
+ * registers across a grid-wide exchange of the partial sums -- replaces vg_bn_act_backward_reduce +
+ * vg_bn_backward_finalize_grouped + vg_bn_act_backward_apply (nn.BatchNorm2d / nn.LeakyReLU / nn.ReLU backward behind
+ * loss.backward(), vaegan_code.py:104, :133; modules main_vae.py:24-25, gan_code.py:22-82).  coeffs: [groups][4][C] as
+ * published by the forward pass (mean | invstd | scale | shift); dgamma / dbeta (+)= per `accumulate`, group after group.
+ * slab: vg_bn_backward_onepass_ws_bytes() bytes of scratch; sync: 16 bytes that are ZERO before the first call and are left
+ * zero by every call (sync[2] != 0 afterwards: a bounded grid-wide wait gave up -- results of that call are invalid).
+ * Returns VG_ENOSUP where _supported() says 0 (the three-launch form then applies). */
+int vg_bn_backward_onepass_supported(int64_t rows, int C, int groups, int dtype);
+int64_t vg_bn_backward_onepass_ws_bytes(int64_t rows, int C, int groups, int dtype);
+int vg_bn_backward_onepass(const void* x, const void* dy, void* dx, const float* coeffs, const float* gamma, float* dgamma,
+                           float* dbeta, int accumulate, float* slab, unsigned* sync, int64_t rows, int C, int groups,
+                           int act, float slope, int dtype, void* stream);
 /* out = a + alpha*b (f32, n elements); used for gradient joins on NCHW images. */
 int vg_axpy(const float* a, const float* b, float alpha, float* out, int64_t n, void* stream);
 /* PSNR/SSIM support for the denoise path lives in vg_image_metrics. */

@@ -719,6 +719,7 @@ def test_bn_backward_finalize_and_apply_in_one_launch(ops, vg_switch, rpg, C, gr
     grouped finalize + apply it replaces (VG_BN_FUSED_FWD=0): dx, and dgamma / dbeta accumulated onto old values in
     group order."""
     dt = G.BF16
+    vg_switch("VG_BN_ONEPASS", "0")          # (the one-launch form of round 4 would take these shapes: its own test below)
     rows = rpg * groups
     g = torch.Generator().manual_seed(rpg * 3 + C)
     x = (torch.randn(rows, C, generator=g) * 1.3 + 0.2).to(DEV).to(torch.bfloat16)
@@ -748,6 +749,87 @@ def test_bn_backward_finalize_and_apply_in_one_launch(ops, vg_switch, rpg, C, gr
     a = F.leaky_relu(z, slope) if act == 2 else F.relu(z)
     (dx_ref,) = torch.autograd.grad(a, xr, dy[:rpg].double().cpu().view(rpg, C, 1, 1))
     torch.testing.assert_close(out["1"][0][:rpg].double().cpu(), dx_ref.view(rpg, C), rtol=5e-2, atol=5e-2)
+
+
+@pytest.mark.parametrize("rpg,C,groups,act,slope,accumulate",
+                         [(2048, 512, 2, 2, 0.2, True), (4096, 256, 1, 1, 0.0, False), (4608, 128, 1, 2, 0.01, True),
+                          (8 * 31 * 31, 32, 1, 2, 0.01, False), (35, 256, 1, 2, 0.2, True), (32, 1024, 1, 1, 0.0, False),
+                          (128 * 16 * 16, 256, 1, 1, 0.0, True), (128 * 16 * 16, 128, 2, 2, 0.2, False),
+                          (128 * 31 * 31, 32, 1, 2, 0.01, True), (3, 8, 1, 0, 0.0, False)])
+def test_bn_backward_in_one_launch_with_a_grid_wide_exchange(ops, vg_switch, rpg, C, groups, act, slope, accumulate):
+    """csrc/bn_onepass.hip (round 4): column sums, coefficients and dx in ONE launch, the x / dy rows of a workgroup held in
+    registers across a grid-wide exchange of the partial sums -- against the column-reduce -> finalize -> apply launches it
+    replaces (VG_BN_ONEPASS=0): dx equal up to rare one-ulp bf16 flips (the double sums associate differently), dgamma /
+    dbeta to fp32 rounding; called three times in a row (the grid counters must return to zero), from full blocks (K = 8,
+    256 workgroups) down to a ragged 3-row tensor; the bounded wait never gives up."""
+    dt = G.BF16
+    rows = rpg * groups
+    g = torch.Generator().manual_seed(rpg * 5 + C)
+    x = (torch.randn(rows, C, generator=g) * 1.3 + 0.2).to(DEV).to(torch.bfloat16)
+    dy = torch.randn(rows, C, generator=g).to(DEV).to(torch.bfloat16)
+    gamma = (torch.randn(C, generator=g) * 0.1 + 1).to(DEV)
+    beta = (torch.randn(C, generator=g) * 0.1).to(DEV)
+    xs = x.float().view(groups, rpg, C)
+    mean, var = xs.mean(1), xs.var(1, unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    scale = gamma * invstd
+    co = torch.stack([mean, invstd, scale, beta - mean * scale], 1).contiguous()
+    seed_g, seed_b = torch.randn(C, generator=g).to(DEV), torch.randn(C, generator=g).to(DEV)
+    vg_switch("VG_BN_ONEPASS", "1")
+    assert importlib.import_module(PKG + "._lib").load().vg_bn_backward_onepass_supported(rows, C, groups, dt) == 1
+    out = {}
+    for mode in ("0", "1", "1", "1"):
+        vg_switch("VG_BN_ONEPASS", mode)
+        dg, db = seed_g.clone(), seed_b.clone()
+        n0 = ops.launch_count()
+        dx = ops.bn_act_backward(x, dy, co, rows, C, rows, gamma, act, slope, dg, db, accumulate, dt)
+        assert (ops.launch_count() - n0 == 1) == (mode == "1")
+        torch.cuda.synchronize()
+        if mode == "1" and "1" in out:
+            assert torch.equal(dx, out["1"][0]) and torch.equal(dg, out["1"][1]) and torch.equal(db, out["1"][2])   # deterministic
+        out[mode] = (dx, dg, db)
+    assert not ops.grid_sync_error(x.device)
+    torch.testing.assert_close(out["1"][1], out["0"][1], rtol=2e-5, atol=2e-4)
+    torch.testing.assert_close(out["1"][2], out["0"][2], rtol=2e-5, atol=2e-4)
+    d = (out["1"][0].float() - out["0"][0].float()).abs()
+    assert float(d.max()) <= 2.0 ** -7 * float(out["0"][0].float().abs().max()) and float((d > 0).float().mean()) < 1e-3
+    xr = x[:rpg].double().cpu().view(rpg, C, 1, 1).requires_grad_(True)
+    z = F.batch_norm(xr, None, None, gamma.double().cpu(), beta.double().cpu(), True, 0.1, 1e-5)
+    a = F.leaky_relu(z, slope) if act == 2 else (F.relu(z) if act == 1 else z)
+    (dx_ref,) = torch.autograd.grad(a, xr, dy[:rpg].double().cpu().view(rpg, C, 1, 1))
+    torch.testing.assert_close(out["1"][0][:rpg].double().cpu(), dx_ref.view(rpg, C), rtol=5e-2, atol=5e-2)
+
+
+def test_bn_backward_in_one_launch_replays_from_a_hipgraph(ops, vg_switch):
+    """The grid counters of bn_onepass.hip go back to zero inside every launch (no memset node): a captured launch replays
+    any number of times with the results of the eager call."""
+    vg_switch("VG_BN_ONEPASS", "1")
+    dt, rows, C = G.BF16, 128 * 8 * 8, 512
+    g = torch.Generator().manual_seed(11)
+    x = (torch.randn(rows, C, generator=g) + 0.1).to(DEV).to(torch.bfloat16)
+    dy = torch.randn(rows, C, generator=g).to(DEV).to(torch.bfloat16)
+    gamma, beta = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
+    mean, var = x.float().mean(0), x.float().var(0, unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    co = torch.stack([mean, invstd, gamma * invstd, beta - mean * gamma * invstd], 0).unsqueeze(0).contiguous()
+    dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    ref = ops.bn_act_backward(x, dy, co, rows, C, rows, gamma, 1, 0.0, dg, db, False, dt).clone()
+    ref_g = dg.clone()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        graph.capture_begin()
+        out = ops.bn_act_backward(x, dy, co, rows, C, rows, gamma, 1, 0.0, dg, db, False, dt)
+        graph.capture_end()
+    torch.cuda.current_stream().wait_stream(s)
+    for _ in range(5):
+        out.zero_(), dg.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref) and torch.equal(dg, ref_g)
+    assert not ops.grid_sync_error(x.device)
 
 
 @pytest.mark.parametrize("B", [1, 37, 128, 300])

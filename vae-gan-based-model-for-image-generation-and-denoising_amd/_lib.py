@@ -136,6 +136,9 @@ SIGNATURES = {
     "vg_mse_forward_backward": (c_int, [_P, _P, _L, _F, _P, _P, _P, _I, _P]),
     "vg_ssim": (c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _I, _P]),
     "vg_axpy": (c_int, [_P, _P, _F, _P, _L, _P]),
+    "vg_bn_backward_onepass_supported": (c_int, [_L, _I, _I, _I]),
+    "vg_bn_backward_onepass_ws_bytes": (c_int64, [_L, _I, _I, _I]),
+    "vg_bn_backward_onepass": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _L, _I, _I, _I, _F, _I, _P]),
     "vg_adam_step": (c_int, [_P, _P, _P, _P, _L, _D, _D, _D, _D, _F, _P, _P]),
     "vg_adam_apply": (c_int, [_P, _P, _P, _P, _L, _D, _D, _D, _F, _P, _P]),
     "vg_rng_advance": (c_int, [_P, _P]),

@@ -169,5 +169,6 @@ struct VgSwitches {
     int wg_dma;            // VG_WG_DMA            1: LDS-DMA staging in wgrad
     int wg_xcd;            // VG_WG_XCD            1: XCD-aware workgroup order in wgrad (2: always)
     int bn_fused_fwd;      // VG_BN_FUSED_FWD      1: BatchNorm finalize folded into the elementwise passes of small layers
+    int bn_onepass;        // VG_BN_ONEPASS        0: (1: BatchNorm backward in one launch with a grid-wide exchange, bn_onepass.hip -- measured slower)
 };
 const VgSwitches& vg_sw();

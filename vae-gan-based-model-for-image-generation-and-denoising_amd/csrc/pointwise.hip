@@ -943,6 +943,7 @@ void read_switches() {
     g_sw.wg_dma = env_int("VG_WG_DMA", 1);
     g_sw.wg_xcd = env_int("VG_WG_XCD", 1);
     g_sw.bn_fused_fwd = env_int("VG_BN_FUSED_FWD", 1);
+    g_sw.bn_onepass = env_int("VG_BN_ONEPASS", 0);
 }
 struct SwitchInit { SwitchInit() { read_switches(); } } g_switch_init;
 }  // namespace

@@ -532,11 +532,44 @@ def channel_stats(x, rows, C, dtype):
     return stats, n.value
 
 
+_GRID_SYNC = {}
+
+
+def grid_sync_words(device) -> torch.Tensor:
+    """The zero-initialised counter words of the kernels that synchronise their whole grid (csrc/bn_onepass.hip): int32[16],
+    [0] arrivals, [1] departures (both back at zero after every launch), [2] sticky error (a bounded wait gave up)."""
+    key = str(device)
+    t = _GRID_SYNC.get(key)
+    if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("grid-sync words would be allocated during graph capture; run a warm-up step first")
+        t = torch.zeros(16, dtype=torch.int32, device=device)
+        _GRID_SYNC[key] = t
+    return t
+
+
+def grid_sync_error(device) -> bool:
+    """True when a grid-wide wait of some earlier launch gave up (results of that launch are invalid).  Synchronises."""
+    t = _GRID_SYNC.get(str(device))
+    return bool(t is not None and int(t[2].item()) != 0)
+
+
 def bn_act_backward(x, dy, coeffs, rows, C, count, gamma, act, slope, dgamma, dbeta, accumulate, dtype, sync=None):
     """Full BN(+act) backward: returns dx (gradient w.r.t. the raw conv output).  coeffs: [groups][4][C]."""
     _need_cuda(x, dy, coeffs)
     lib = L.load()
     groups = coeffs.shape[0]
+    if sync is None and x.shape[-1] == C and lib.vg_bn_backward_onepass_supported(rows, C, groups, dtype):
+        # one launch: the workgroups keep their x / dy rows in registers across a grid-wide exchange of the partial sums
+        # (csrc/bn_onepass.hip): 3 tensor-sized streams instead of 5, no finalize launch
+        _bn_bytes(3, x.numel(), dtype)
+        slab = WS.get("bn1pass", lib.vg_bn_backward_onepass_ws_bytes(rows, C, groups, dtype), x.device)
+        dx = torch.empty_like(x)
+        L.check(lib.vg_bn_backward_onepass(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), coeffs.data_ptr(), L.ptr(gamma),
+                                           L.ptr(dgamma), L.ptr(dbeta), 1 if accumulate else 0, slab.data_ptr(),
+                                           grid_sync_words(x.device).data_ptr(), rows, C, groups, act, slope, dtype,
+                                           L.stream_ptr()), "vg_bn_backward_onepass")
+        return dx
     n = c_int(0)
     cap = 2048
     _bn_bytes(5, x.numel(), dtype)
