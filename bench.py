@@ -473,7 +473,10 @@ def main():
            "config": {"workload": f"CelebA-shaped {S}x{S} VAE-GAN full train step (E+G+5xD fwd, all bwd, 4 Adam), "
                                   f"batch {B}/GPU, global batch {B * world}", "img_size": S, "per_gpu_batch": B,
                       "global_batch": B * world, "parallelism": f"dp{world}", "epoch_kl_weight": 0.1,
-                      "elide_dead_grads": bool(args.elide_dead_grads), "hip_graph": use_graph},
+                      "elide_dead_grads": bool(args.elide_dead_grads), "hip_graph": use_graph,
+                      # graphs one iteration is replayed from: 1 = the whole iteration incl. its RCCL collectives (N > 1:
+                      # captured inside the graph); > 1 = cut at the hand-offs to the reducer (gloo rehearsals, fallback)
+                      "hip_graph_segments": (len(tr._graph[1]) if (use_graph and tr._graph is not None) else 0)},
            # kernel launches of libvaegan_hip.so per iteration (vg_launch_count over the eager pass that follows the timed
            # region; the replayed graph holds the same launches).  Round 3: 193 by rocprofv3.
            "kernel_launches_per_step": launches_per_step,

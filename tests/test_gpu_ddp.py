@@ -27,13 +27,13 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _launch(tmp_path, world, S, GB, steps, sync_bn, graph, lr=2e-4, backend="gloo"):
+def _launch(tmp_path, world, S, GB, steps, sync_bn, graph, lr=2e-4, backend="gloo", extra_env=None):
     out = str(tmp_path / f"w{world}_s{sync_bn}_g{graph}_{backend}.npz")
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY="0", VAEGAN_TEST_BACKEND=backend)
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", VAEGAN_TEST_BACKEND=backend, **(extra_env or {}))
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_ddp_gpu_worker.py"), out, str(S), str(GB),
                                        str(steps), str(sync_bn), str(graph), repr(lr)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT))
@@ -172,14 +172,17 @@ def test_syncbn_graph_replay_equals_eager_under_a_process_group(tmp_path):
     assert int(eager[0]["stat_collectives"]) == int(graph[0]["stat_collectives"]) > 0
 
 
-@pytest.mark.parametrize("sync_bn,graph", [(1, 0), (0, 1), (1, 1)])
-def test_single_rank_over_rccl_equals_single_process(tmp_path, sync_bn, graph):
+@pytest.mark.parametrize("sync_bn,graph,capture", [(1, 0, 1), (0, 1, 1), (1, 1, 1), (0, 1, 0), (1, 1, 0)])
+def test_single_rank_over_rccl_equals_single_process(tmp_path, sync_bn, graph, capture):
     """The collectives themselves over RCCL (backend "nccl"), which the shared-GPU gloo tests above cannot reach: one
-    rank per GPU means one rank here.  SyncBN mode (f64 statistics all-reduces inside every BatchNorm, eager) and
-    throughput mode (flat-buffer gradient all-reduces between hipGraph segments, 3 iterations: eager, capture,
-    replay).  With one rank every reduction is the identity, so the run must reproduce the single-process one."""
+    rank per GPU means one rank here.  SyncBN mode (f64 statistics all-reduces inside every BatchNorm) and throughput mode
+    (flat-buffer gradient all-reduces), 3 iterations: eager, capture, replay -- with the collectives recorded INSIDE the
+    hipGraph (round 4, the default over RCCL: ONE graph per iteration) and with the graph cut at every collective
+    (VAEGAN_DDP_CAPTURE=0: 6 segments).  With one rank every reduction is the identity, so the run must reproduce the
+    single-process one; the reducer's counters must count replayed collectives too."""
     S, GB, steps = 64, 8, (1 if (sync_bn and not graph) else 3)
-    r0 = _launch(tmp_path, 1, S, GB, steps, sync_bn, graph, backend="nccl")[0]
+    r0 = _launch(tmp_path, 1, S, GB, steps, sync_bn, graph, backend="nccl",
+                 extra_env={"VAEGAN_DDP_CAPTURE": str(capture)})[0]
     one = _single_process(S, GB, steps, 2e-4)
     tol = [1e-5, 1e-5, 5e-4, 1e-5, 5e-4]           # first iteration (FIRST_STEP_TOL)
     for i, t in enumerate(tol):
@@ -193,7 +196,7 @@ def test_single_rank_over_rccl_equals_single_process(tmp_path, sync_bn, graph):
         assert list(r0["buckets"]) == [1, 2, 1]
         assert int(r0["collectives"]) == 5 * steps
         if graph:
-            assert int(r0["segments"]) == 6
+            assert int(r0["segments"]) == (1 if capture else 6)
     for k in one:
         if k.startswith("buf_") and "num_batches" in k:
             assert int(r0[k]) == int(one[k]), k

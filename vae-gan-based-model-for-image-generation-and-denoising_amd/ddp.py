@@ -100,6 +100,15 @@ class GradReducer:
         self.bytes_reduced = 0
         self.collectives = 0
         self.stat_collectives = 0
+        # RCCL's collectives can be recorded into a hipGraph (PyTorch's NCCL work objects fork / join the capturing stream
+        # through events: tools/rccl_capture_probe.py); gloo does host-side work and cannot.  VAEGAN_DDP_CAPTURE=0 forces
+        # the segmented form (graph cut at every bucket launch) also over RCCL.
+        import os
+        try:
+            backend = dist.get_backend(process_group)
+        except Exception:
+            backend = ""
+        self.capturable = backend == "nccl" and os.environ.get("VAEGAN_DDP_CAPTURE", "1") != "0"
 
     def attach(self, *optimizers) -> None:
         """Fold the 1/world_size average into each optimizer's fused step."""
@@ -157,6 +166,10 @@ class GradReducer:
 
     def outstanding(self) -> int:
         return sum(len(v) for v in self._pending.values())
+
+    def forget_pending(self) -> None:
+        """Drop work handles created inside a hipGraph capture that was abandoned (they belong to no executed launch)."""
+        self._pending.clear()
 
     def all_reduce_sum(self, t: torch.Tensor) -> None:
         """In-place SUM over ranks of a small statistics tensor (synchronised BatchNorm)."""

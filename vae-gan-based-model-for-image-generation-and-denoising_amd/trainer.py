@@ -74,6 +74,7 @@ class VAEGANTrainer:
         self._graph = None              # (key, [hipGraph segments], [collectives between them], static in, static out)
         self._warm_key = None
         self._cut_hook = None           # set while capturing: splits the iteration into graph segments
+        self._inline_failed = False     # capturing the collectives inside the graph failed once: use the segmented form
 
     def train(self):
         self.E.train(), self.G.train(), self.D.train()                                         # :56-58
@@ -304,7 +305,7 @@ class VAEGANTrainer:
             self._noise_stream(real.device)         # exists (and is keyed on the current seed) before the key is formed
         key = self._capture_key(real, epoch, inject)
         if self._graph is not None and self._graph[0] == key:
-            _, graphs, cuts, sin, sout = self._graph
+            _, graphs, cuts, sin, sout = self._graph[:5]
             if real.data_ptr() != sin[0].data_ptr():    # a batch assembled in graph_input() needs no copy
                 sin[0].copy_(real)
             if inject:
@@ -318,6 +319,33 @@ class VAEGANTrainer:
             self._graph = None
             return self.train_step(real, epoch, eps_z, eps_real, eps_recon)
         sin = [real.clone()] + ([eps_z.clone(), eps_real.clone(), eps_recon.clone()] if inject else [None] * 3)
+        # Collectives INSIDE the graph (round 4): RCCL's all-reduces are capturable on this stack (PyTorch 2.10 / RCCL 2.26:
+        # tools/rccl_capture_probe.py) -- the asynchronous bucket launches fork onto RCCL's stream and the waits join it
+        # back, all as graph dependencies, so the iteration stays ONE graph and no hand-off costs a graph boundary (a cut
+        # is ~29 us of idle GPU, 5 per iteration: DESIGN.md section 7).  Reducers that cannot be captured (gloo: host-side
+        # work) keep the segmented form; if the inline capture fails on some stack the segmented one is tried next.
+        inline = self.reducer is not None and bool(getattr(self.reducer, "capturable", False)) and not self._inline_failed
+        try:
+            graphs, cuts, sout, dcount = self._capture(sin, epoch, inline)
+        except Exception as ex:                     # noqa: BLE001
+            if not inline:
+                raise
+            import sys
+            print(f"[vaegan_amd] capturing the gradient collectives inside the hipGraph failed ({ex!r}); "
+                  f"falling back to graph segments cut at the collectives", file=sys.stderr)
+            self._inline_failed = True
+            graphs, cuts, sout, dcount = self._capture(sin, epoch, False)
+        self._graph = (key, graphs, cuts, sin, sout, dcount)
+        self._replay(graphs, cuts)
+        self._advance_host_counters()
+        self.losses = sout
+        return sout
+
+    def _capture(self, sin, epoch, inline):
+        """Capture one iteration on the static inputs `sin`.  inline: the reducer's collectives are recorded into the graph
+        (one segment); else the graph is cut at every hand-off to the reducer and the collectives run between the segment
+        replays.  Returns (graphs, cuts, static output, per-iteration deltas of the reducer's counters).  Executes nothing;
+        on failure the trainer is exactly where it was."""
         for eng in (self.E._engine, self.G._engine, self.D._engine):
             eng.invalidate()                       # the captured sequence must contain the operand re-packs
         # Nothing of torch.distributed may be in flight while a stream is capturing: c10d's watchdog thread polls
@@ -331,9 +359,11 @@ class VAEGANTrainer:
             raise RuntimeError("hipGraph capture refused: the gradient reducer still has collectives in flight")
         ticks = [m._engine.pending_bn_ticks for m in (self.E, self.G, self.D)]
         steps = [o.steps for o in (self.opt_E, self.opt_G, self.opt_D)]
+        cnames = ("collectives", "bytes_reduced", "stat_collectives")
+        counts = [getattr(self.reducer, n, 0) for n in cnames] if self.reducer is not None else None
         graphs, cuts = [], []
         pool = torch.cuda.graph_pool_handle()
-        cap = torch.cuda.Stream(device=real.device)
+        cap = torch.cuda.Stream(device=sin[0].device)
         cap.wait_stream(torch.cuda.current_stream())
 
         def begin():
@@ -344,8 +374,11 @@ class VAEGANTrainer:
             g.capture_begin(pool=pool, capture_error_mode="thread_local")
             graphs.append(g)
 
-        def cut(collective):                       # close this segment, remember the collective, open the next
-            graphs[-1].capture_end()
+        def cut(collective):
+            if inline:
+                collective()                       # recorded: a fork onto / a join from RCCL's stream inside the graph
+                return
+            graphs[-1].capture_end()               # close this segment, remember the collective, open the next
             cuts.append(collective)
             begin()
 
@@ -354,6 +387,13 @@ class VAEGANTrainer:
                 m._engine.pending_bn_ticks = t
             for o, st in zip((self.opt_E, self.opt_G, self.opt_D), steps):
                 o.steps = st
+            deltas = None
+            if counts is not None:
+                deltas = [getattr(self.reducer, n, 0) - c for n, c in zip(cnames, counts)]
+                for n, c in zip(cnames, counts):
+                    if hasattr(self.reducer, n):
+                        setattr(self.reducer, n, c)
+            return deltas
 
         with no_gc_while_capturing(), torch.cuda.stream(cap):
             self._cut_hook = cut
@@ -369,6 +409,8 @@ class VAEGANTrainer:
                 except Exception:
                     pass
                 restore_host_counters()
+                if self.reducer is not None and hasattr(self.reducer, "forget_pending"):
+                    self.reducer.forget_pending()
                 self._graph, self._warm_key = None, None
                 for eng in (self.E._engine, self.G._engine, self.D._engine):
                     eng.invalidate()
@@ -376,12 +418,9 @@ class VAEGANTrainer:
             finally:
                 self._cut_hook = None
         torch.cuda.current_stream().wait_stream(cap)
-        restore_host_counters()                    # then replay for real
-        self._graph = (key, graphs, cuts, sin, sout)
-        self._replay(graphs, cuts)
-        self._advance_host_counters()
-        self.losses = sout
-        return sout
+        deltas = restore_host_counters()           # then replay for real
+        dcount = dict(zip(cnames, deltas)) if (inline and deltas is not None) else None
+        return graphs, cuts, sout, dcount
 
     @staticmethod
     def _replay(graphs, cuts) -> None:
@@ -392,7 +431,13 @@ class VAEGANTrainer:
 
     def _advance_host_counters(self) -> None:
         """What one iteration does to host-side mirrors: BatchNorm forward counts (E 1, G 1, D 2*d_iters+1) and
-        optimizer step counts (the authoritative Adam step counter lives on the device)."""
+        optimizer step counts (the authoritative Adam step counter lives on the device); with collectives captured
+        inside the graph also the reducer's statistics counters (a replay runs no Python of the reducer)."""
+        dcount = self._graph[5] if (self._graph is not None and len(self._graph) > 5) else None
+        if dcount and self.reducer is not None:
+            for n, d in dcount.items():
+                if hasattr(self.reducer, n):
+                    setattr(self.reducer, n, getattr(self.reducer, n) + d)
         if self.E.training:
             self.E._engine.pending_bn_ticks += 1
             self.G._engine.pending_bn_ticks += 1
