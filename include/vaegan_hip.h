@@ -417,6 +417,17 @@ int vg_ssim(const float* a, const float* b, int B, int C, int H, int W, float* o
  * ---------------------------------------------------------------------------------------- */
 int vg_rng_advance(uint64_t* rng, void* stream);
 int vg_randn(float* out, int64_t n, const uint64_t* rng, int draw, void* stream);
+/* One pass over x (NCHW f32) -> y_noisy = x + sigma * noise AND y_plain = x, both NHWC bf16 with CP = 8 channels: the
+ * Encoder's input and the Discriminator's noisy real batch (vaegan_code.py:74, :91).  Exactly one of eps (injected noise,
+ * NCHW f32) / rng (+ draw).  VG_ENOSUP unless bf16, CP == 8, C <= 4, H * W % 4 == 0 (convert twice then). */
+int vg_nchw_to_nhwc_pair(const float* x, const float* eps, const uint64_t* rng, int draw, float sigma, void* y_noisy,
+                         void* y_plain, int B, int C, int H, int W, int CP, int dtype, void* stream);
+/* vg_mse_forward_backward in two halves: the partial sums (+ gradient) here, the final sum inside the KL launch below
+ * (vaegan_code.py:113-114 are evaluated back to back; the separate one-wave finalize launch was 4.7 us). */
+int vg_mse_partial(const float* a, const float* b, int64_t n, float gscale, float* d_a, float* ws, int ws_capacity,
+                   int* nparts_out, void* stream);
+int vg_kl_forward_mse_final(const void* mulv, const float* lv_clamped, int B, int L, int MP, float divisor, float* out,
+                            const float* mse_ws, int mse_nparts, int64_t mse_n, float* mse_loss, int dtype, void* stream);
 int vg_nchw_to_nhwc_rng(const float* x, const uint64_t* rng, int draw, float sigma, void* y,
                         int B, int C, int H, int W, int CP, int dtype, void* stream);          /* vaegan_code.py:91 */
 int vg_nhwc_tanh_to_nchw_noisy_rng(const void* x, float* y_nchw, const uint64_t* rng, int draw, float sigma,
@@ -468,7 +479,13 @@ int vg_adam_apply(float* p, const float* g, float* m, float* v, int64_t n, doubl
                   float grad_scale, const float* state /* prepared by vg_step_prologue */, void* stream);
 #define VG_PROLOGUE_MAX 4
 int vg_step_prologue(uint64_t* rng, float* const* states, const double* lr, const double* beta1, const double* beta2,
-                     int n, void* stream);
+                     int n, float* zero /* nzero floats set to 0 (the iteration's loss slots), or NULL */, int nzero,
+                     void* stream);
+/* The Encoder's and the Generator's optimizer step of one iteration (vaegan_code.py:134-135) in ONE launch: arrays of two
+ * (p, g, m, v, n, betas, eps, grad_scale, prepared state); arithmetic and per-element work split of vg_adam_apply. */
+int vg_adam_apply2(float* const* p, const float* const* g, float* const* m, float* const* v, const int64_t* n,
+                   const double* beta1, const double* beta2, const double* eps, const float* grad_scale,
+                   const float* const* state, void* stream);
 
 #ifdef __cplusplus
 }

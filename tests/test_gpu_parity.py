@@ -533,6 +533,45 @@ def test_step_prologue_is_bit_identical_to_per_optimizer_prepares(dtype, B, grap
     assert outs[0][4] == outs[1][4]
 
 
+@pytest.mark.parametrize("dtype,B,graphed,inject", [("fp32", 8, False, True), ("bf16", 128, False, True), ("bf16", 128, True, True),
+                                                    ("bf16", 128, True, False)])
+def test_merged_small_launches_are_bit_identical_to_the_separate_ones(dtype, B, graphed, inject):
+    """Round 4: four pairs of small launches per iteration merged -- Encoder-input conversion + noisy real batch (one pass
+    over the images), the MSE's final sum inside the KL launch, the Encoder's + the Generator's Adam step, the loss slots'
+    memset inside the step prologue (vaegan_code.py:74/:91, :113-114, :134-135) -- against VAEGANTrainer with
+    merge_small_launches = False: losses, parameters, Adam moments and counters of three (four) iterations bit for bit,
+    eager and replayed, with injected and with in-kernel noise; and the launch count drops by four (bf16)."""
+    import importlib
+    ops = importlib.import_module(V.Encoder.__module__.rsplit(".", 1)[0] + ".ops")
+    outs, counts = [], []
+    for merged in (True, False):
+        e, g, d, tr = build(64, dtype=dtype)
+        torch.cuda.manual_seed(77)
+        tr.merge_small_launches = merged
+        fn = tr.train_step_graphed if graphed else tr.train_step
+        ls = []
+        for step in range(4 if graphed else 3):
+            real, ez, er, ec = (t.to(DEV) for t in make_inputs(B, 64, 4600 + step))
+            n0 = ops.launch_count()
+            out = fn(real, 60, ez, er, ec) if inject else fn(real, 60)
+            ls.append(out[:5].clone())
+            if step == 0:
+                counts.append(ops.launch_count() - n0)       # (the first call is eager in both modes)
+        torch.cuda.synchronize()
+        outs.append((torch.stack(ls).cpu(), [o.flat_p.cpu().clone() for o in (tr.opt_E, tr.opt_G, tr.opt_D)],
+                     [o.exp_avg.cpu().clone() for o in (tr.opt_E, tr.opt_G, tr.opt_D)],
+                     [o.exp_avg_sq.cpu().clone() for o in (tr.opt_E, tr.opt_G, tr.opt_D)],
+                     [(o.steps, float(o.state_dev[0]), float(o.state_dev[1]), float(o.state_dev[2]))
+                      for o in (tr.opt_E, tr.opt_G, tr.opt_D)]))
+    for it in range(outs[0][0].shape[0]):
+        assert torch.equal(outs[0][0][it], outs[1][0][it]), f"losses of iteration {it + 1} differ: {outs[0][0][it] - outs[1][0][it]}"
+    for k in (1, 2, 3):
+        for a, b in zip(outs[0][k], outs[1][k]):
+            assert torch.equal(a, b)
+    assert outs[0][4] == outs[1][4]
+    assert counts[1] - counts[0] == (3 if dtype == "bf16" else 2), counts     # (+ the memset, which is not a library launch)
+
+
 class _LocalReducer:
     """world_size-1 stand-in with the whole-buffer GradReducer surface: lets the single GPU exercise the SEGMENTED
     graph path (collectives between hipGraph segments) and records how the trainer drives it."""

@@ -175,10 +175,20 @@ def test_c_abi_rejects_bad_arguments_on_host():
     assert lib.vg_wgrad_ws_bytes(ctypes.byref(w), 0) == -1
     assert lib.vg_adam_step(None, None, None, None, 0, 1e-3, 0.9, 0.999, 1e-8, 1.0, None, None) == -1
     # the iteration prologue: nothing to do at all, too many optimizers, a NULL state
-    assert lib.vg_step_prologue(None, None, None, None, None, 0, None) == -1
-    assert lib.vg_step_prologue(None, None, None, None, None, 5, None) == -1
+    assert lib.vg_step_prologue(None, None, None, None, None, 0, None, 0, None) == -1
+    assert lib.vg_step_prologue(None, None, None, None, None, 5, None, 0, None) == -1
     one = (ctypes.c_double * 1)(1e-3)
-    assert lib.vg_step_prologue(None, (ctypes.c_void_p * 1)(None), one, one, one, 1, None) == -1
+    assert lib.vg_step_prologue(None, (ctypes.c_void_p * 1)(None), one, one, one, 1, None, 0, None) == -1
+    # round 4: loss slots to zero without a pointer, a negative learning rate (no longer an overload for "prepared"), the
+    # prepared form and the two-optimizer form without buffers, the one-launch BatchNorm backward without workspace
+    assert lib.vg_step_prologue(None, None, None, None, None, 0, None, 8, None) == -1
+    buf = ctypes.c_void_p(64)
+    assert lib.vg_adam_step(buf, buf, buf, buf, 4, -1.0, 0.9, 0.999, 1e-8, 1.0, buf, None) == -1
+    assert lib.vg_adam_apply(None, None, None, None, 0, 0.9, 0.999, 1e-8, 1.0, None, None) == -1
+    assert lib.vg_adam_apply2(None, None, None, None, None, None, None, None, None, None, None) == -1
+    assert lib.vg_bn_backward_onepass(None, None, None, None, None, None, None, 0, None, None, 0, 64, 1, 0, 0.0, 1, None) == -1
+    assert lib.vg_mse_partial(None, None, 0, 1.0, None, None, 0, None, None) == -1
+    assert lib.vg_nchw_to_nhwc_pair(None, None, None, 0, 0.0, None, None, 0, 0, 0, 0, 8, 1, None) == -1
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

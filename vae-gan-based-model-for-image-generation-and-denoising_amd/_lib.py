@@ -18,6 +18,7 @@ VG_ACT_NONE, VG_ACT_RELU, VG_ACT_LRELU, VG_ACT_TANH = 0, 1, 2, 3
 VG_MAX_PHASE = 4
 ABI_VERSION = 10
 
+VG_ENOSUP = -3
 _ERR = {-1: "VG_EINVAL (bad shape/size/flag)", -2: "VG_EALIGN (16-byte contract violated)",
         -3: "VG_ENOSUP (unsupported configuration)"}
 
@@ -142,7 +143,11 @@ SIGNATURES = {
     "vg_adam_step": (c_int, [_P, _P, _P, _P, _L, _D, _D, _D, _D, _F, _P, _P]),
     "vg_adam_apply": (c_int, [_P, _P, _P, _P, _L, _D, _D, _D, _F, _P, _P]),
     "vg_rng_advance": (c_int, [_P, _P]),
-    "vg_step_prologue": (c_int, [_P, _P, _P, _P, _P, _I, _P]),
+    "vg_step_prologue": (c_int, [_P, _P, _P, _P, _P, _I, _P, _I, _P]),
+    "vg_adam_apply2": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "vg_nchw_to_nhwc_pair": (c_int, [_P, _P, _P, _I, _F, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "vg_mse_partial": (c_int, [_P, _P, _L, _F, _P, _P, _I, POINTER(c_int), _P]),
+    "vg_kl_forward_mse_final": (c_int, [_P, _P, _I, _I, _I, _F, _P, _P, _I, _L, _P, _I, _P]),
     "vg_randn": (c_int, [_P, _L, _P, _I, _P]),
     "vg_nchw_to_nhwc_rng": (c_int, [_P, _P, _I, _F, _P, _I, _I, _I, _I, _I, _I, _P]),
     "vg_nhwc_tanh_to_nchw_noisy_rng": (c_int, [_P, _P, _P, _I, _F, _P, _I, _I, _I, _I, _I, _I, _P]),

@@ -210,6 +210,8 @@ __global__ void adam_prep_kernel(float* state, double lr, double beta1, double b
 // step counters / bias corrections of up to VG_PROLOGUE_MAX optimizers (what adam_prep_kernel does per optimizer).
 struct PrologueArgs {
     unsigned long long* rng;
+    float* zero;                          // loss slots of the iteration, zeroed here instead of by a memset node
+    int nzero;
     float* state[VG_PROLOGUE_MAX];
     double lr[VG_PROLOGUE_MAX], beta1[VG_PROLOGUE_MAX], beta2[VG_PROLOGUE_MAX];
     int n;
@@ -217,6 +219,7 @@ struct PrologueArgs {
 __global__ void step_prologue_kernel(const PrologueArgs a) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (a.rng != nullptr) a.rng[1] += 1ull;
+    for (int i = 0; i < a.nzero; ++i) a.zero[i] = 0.f;
     for (int i = 0; i < a.n; ++i) {
         float* state = a.state[i];
         const double t = (double)state[0] + 1.0;
@@ -252,6 +255,56 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
     // tail (n not a multiple of 4)
     if (blockIdx.x == 0) {
+        for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) {
+            const float gr = g[i] * gscale;
+            float mi = m[i], vi = v[i];
+            mi = mi + w1 * (gr - mi);
+            vi = vi * beta2 + w2 * (gr * gr);
+            const float denom = sqrtf(vi) / bc2_sqrt + eps;
+            p[i] = p[i] - step_size * (mi / denom);
+            m[i] = mi;
+            v[i] = vi;
+        }
+    }
+}
+
+// Two optimizers in ONE launch (the Encoder's and the Generator's step at the end of the iteration, vaegan_code.py:134-135):
+// the first nb0 workgroups walk buffer 0, the rest buffer 1 -- the arithmetic per element is adam_kernel's.
+struct Adam2Args {
+    float* p[2]; const float* g[2]; float* m[2]; float* v[2]; const float* state[2];
+    int64_t n[2];
+    float w1[2], beta2[2], w2[2], eps[2], gscale[2];
+    int nb0;
+};
+__global__ __launch_bounds__(256) void adam2_kernel(const Adam2Args a) {
+    const int which = blockIdx.x < a.nb0 ? 0 : 1;
+    const int bid = which == 0 ? blockIdx.x : blockIdx.x - a.nb0;
+    const int nb = which == 0 ? a.nb0 : (int)gridDim.x - a.nb0;
+    float* __restrict__ p = a.p[which]; const float* __restrict__ g = a.g[which];
+    float* __restrict__ m = a.m[which]; float* __restrict__ v = a.v[which];
+    const float w1 = a.w1[which], beta2 = a.beta2[which], w2 = a.w2[which], eps = a.eps[which], gscale = a.gscale[which];
+    const float step_size = a.state[which][1];
+    const float bc2_sqrt = a.state[which][2];
+    const int64_t n = a.n[which], n4 = n / 4;
+    for (int64_t i = (int64_t)bid * blockDim.x + threadIdx.x; i < n4; i += (int64_t)nb * blockDim.x) {
+        float4 pp = reinterpret_cast<float4*>(p)[i];
+        float4 gg = reinterpret_cast<const float4*>(g)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i];
+        float4 vv = reinterpret_cast<float4*>(v)[i];
+        float* P = &pp.x; float* G = &gg.x; float* Mv = &mm.x; float* V = &vv.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gr = G[k] * gscale;
+            Mv[k] = Mv[k] + w1 * (gr - Mv[k]);
+            V[k] = V[k] * beta2 + w2 * (gr * gr);
+            const float denom = sqrtf(V[k]) / bc2_sqrt + eps;
+            P[k] = P[k] - step_size * (Mv[k] / denom);
+        }
+        reinterpret_cast<float4*>(p)[i] = pp;
+        reinterpret_cast<float4*>(m)[i] = mm;
+        reinterpret_cast<float4*>(v)[i] = vv;
+    }
+    if (bid == 0) {
         for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) {
             const float gr = g[i] * gscale;
             float mi = m[i], vi = v[i];
@@ -331,11 +384,34 @@ extern "C" int vg_adam_apply(float* p, const float* g, float* m, float* v, int64
     return adam_launch(p, g, m, v, n, beta1, beta2, eps, grad_scale, const_cast<float*>(state), vg_stream(stream));
 }
 
+extern "C" int vg_adam_apply2(float* const* p, const float* const* g, float* const* m, float* const* v, const int64_t* n,
+                              const double* beta1, const double* beta2, const double* eps, const float* grad_scale,
+                              const float* const* state, void* stream) {
+    VG_CHECK_ARG(p && g && m && v && n && beta1 && beta2 && eps && grad_scale && state, VG_EINVAL);
+    Adam2Args a{};
+    int nb[2];
+    for (int i = 0; i < 2; ++i) {
+        VG_CHECK_ARG(p[i] && g[i] && m[i] && v[i] && state[i] && n[i] > 0, VG_EINVAL);
+        VG_CHECK_ARG(vg_aligned16(p[i]) && vg_aligned16(g[i]) && vg_aligned16(m[i]) && vg_aligned16(v[i]), VG_EALIGN);
+        a.p[i] = p[i]; a.g[i] = g[i]; a.m[i] = m[i]; a.v[i] = v[i]; a.state[i] = state[i]; a.n[i] = n[i];
+        a.w1[i] = (float)(1.0 - beta1[i]); a.beta2[i] = (float)beta2[i]; a.w2[i] = (float)(1.0 - beta2[i]);
+        a.eps[i] = (float)eps[i]; a.gscale[i] = grad_scale[i];
+        int64_t b = (n[i] / 4 + 255) / 256;
+        nb[i] = (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));       // adam_launch's grid: same elements per thread, same results
+    }
+    a.nb0 = nb[0];
+    hipLaunchKernelGGL(adam2_kernel, dim3(nb[0] + nb[1]), dim3(256), 0, vg_stream(stream), a);
+    return VG_LAUNCH_RC();
+}
+
 extern "C" int vg_step_prologue(uint64_t* rng, float* const* states, const double* lr, const double* beta1,
-                                const double* beta2, int n, void* stream) {
+                                const double* beta2, int n, float* zero, int nzero, void* stream) {
     VG_CHECK_ARG(n >= 0 && n <= VG_PROLOGUE_MAX && (n == 0 || (states && lr && beta1 && beta2)) && (rng || n > 0), VG_EINVAL);
+    VG_CHECK_ARG(nzero >= 0 && nzero <= 64 && (nzero == 0 || zero != nullptr), VG_EINVAL);
     PrologueArgs a{};
     a.rng = (unsigned long long*)rng;
+    a.zero = zero;
+    a.nzero = nzero;
     a.n = n;
     for (int i = 0; i < n; ++i) {
         VG_CHECK_ARG(states[i] != nullptr && lr[i] >= 0.0, VG_EINVAL);

@@ -43,7 +43,8 @@ __global__ __launch_bounds__(256) void randn_fill_kernel(float* __restrict__ out
 template <int DT>
 __global__ __launch_bounds__(256) void nchw_to_nhwc_x4_kernel(const float* __restrict__ x, const NoiseSrc eps, float sigma,
                                                               void* __restrict__ y, int64_t npix4, int C, int HW,
-                                                              float lo, float hi, float* __restrict__ y_nchw) {
+                                                              float lo, float hi, float* __restrict__ y_nchw,
+                                                              void* __restrict__ y_plain = nullptr) {
     static_assert(DT == VG_BF16, "8 bf16 channels = one 16-byte pixel");
     const bool noisy = eps.eps != nullptr || eps.rng != nullptr;
     for (int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i4 < npix4; i4 += (int64_t)gridDim.x * blockDim.x) {
@@ -51,12 +52,15 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_x4_kernel(const float* __res
         const int64_t b = i / HW;
         const int64_t hw = i - b * HW;
         float v[4][4];                                          // [pixel][channel]
+        float q[4][4];                                          // the same pixels without the noise (y_plain)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             if (c < C) {
                 const int64_t src = (b * C + c) * HW + hw;
                 const float4 t4 = *reinterpret_cast<const float4*>(x + src);
                 float t[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+                for (int p = 0; p < 4; ++p) q[p][c] = t[p];
                 if (noisy) {
                     const Normal4 nz = noise4_at(eps, src);
 #pragma unroll
@@ -67,7 +71,7 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_x4_kernel(const float* __res
                 if (y_nchw) *reinterpret_cast<float4*>(y_nchw + src) = float4{t[0], t[1], t[2], t[3]};
             } else {
 #pragma unroll
-                for (int p = 0; p < 4; ++p) v[p][c] = 0.f;
+                for (int p = 0; p < 4; ++p) { v[p][c] = 0.f; q[p][c] = 0.f; }
             }
         }
 #pragma unroll
@@ -77,6 +81,11 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_x4_kernel(const float* __res
             o[1] = (uint32_t)ElemT<VG_BF16>::from_f32(v[p][2]) | ((uint32_t)ElemT<VG_BF16>::from_f32(v[p][3]) << 16);
             o[2] = 0u; o[3] = 0u;
             *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(y) + (i + p) * 16) = o;
+            if (y_plain) {
+                o[0] = (uint32_t)ElemT<VG_BF16>::from_f32(q[p][0]) | ((uint32_t)ElemT<VG_BF16>::from_f32(q[p][1]) << 16);
+                o[1] = (uint32_t)ElemT<VG_BF16>::from_f32(q[p][2]) | ((uint32_t)ElemT<VG_BF16>::from_f32(q[p][3]) << 16);
+                *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(y_plain) + (i + p) * 16) = o;
+            }
         }
     }
 }
@@ -225,9 +234,19 @@ __global__ void reparam_fwd_kernel(const void* __restrict__ mulv, const NoiseSrc
 
 template <int DT>
 __global__ __launch_bounds__(1024) void kl_kernel(const void* __restrict__ mulv, const float* __restrict__ lvc, int B,
-                                                  int L, int MP, float divisor, float* __restrict__ out) {
+                                                  int L, int MP, float divisor, float* __restrict__ out,
+                                                  const float* __restrict__ mse_ws, int mse_nparts, double mse_n,
+                                                  float* __restrict__ mse_loss) {
     // one workgroup (a single scalar result, fixed summation order); 1024 threads keep the B*L-element loop short
     __shared__ double red[16];
+    if (mse_ws != nullptr && threadIdx.x < 64) {
+        // the second stage of vg_mse_forward_backward rides along (its own launch was 4.7 us for 1024 partials): wave 0,
+        // exactly mse_final_kernel's arithmetic and order
+        double s = 0.0;
+        for (int i = threadIdx.x; i < mse_nparts; i += 64) s += (double)mse_ws[i];
+        s = wave_sum_d(s);
+        if (threadIdx.x == 0) mse_loss[0] = (float)(s / mse_n);
+    }
     double s = 0.0;
     const int total = B * L;
     int i = threadIdx.x;
@@ -671,6 +690,25 @@ extern "C" int vg_nchw_to_nhwc_rng(const float* x, const uint64_t* rng, int draw
     return VG_LAUNCH_RC();
 }
 
+// x (NCHW f32) -> y_noisy = x + sigma * eps AND y_plain = x, both NHWC bf16 with 8 channels, in one pass over x: the
+// Encoder's input and the Discriminator's noisy real batch (vaegan_code.py:74 and :91) are the same image batch.
+// eps: injected noise tensor or NULL; rng / draw: in-kernel generator (exactly one of eps / rng).  VG_ENOSUP where the
+// four-pixel kernel does not apply (the caller then converts twice).
+extern "C" int vg_nchw_to_nhwc_pair(const float* x, const float* eps, const uint64_t* rng, int draw, float sigma,
+                                    void* y_noisy, void* y_plain, int B, int C, int H, int W, int CP, int dtype,
+                                    void* stream) {
+    VG_CHECK_ARG(x && y_noisy && y_plain && ((eps != nullptr) != (rng != nullptr)) && draw >= 0 && draw < 256 && B > 0 &&
+                 C > 0 && H > 0 && W > 0, VG_EINVAL);
+    if (!(dtype == VG_BF16 && CP == 8 && C <= 4 && (H * W) % 4 == 0 && vg_aligned16(x) && vg_aligned16(y_noisy) &&
+          vg_aligned16(y_plain) && (eps == nullptr || vg_aligned16(eps))))
+        return VG_ENOSUP;
+    const int64_t npix = (int64_t)B * H * W;
+    hipLaunchKernelGGL(nchw_to_nhwc_x4_kernel<VG_BF16>, dim3(blocks_for(npix / 4)), dim3(256), 0, vg_stream(stream), x,
+                       (NoiseSrc{eps, (const unsigned long long*)rng, (uint32_t)draw}), sigma, y_noisy, npix / 4, C, H * W,
+                       -3.0e38f, 3.0e38f, (float*)nullptr, y_plain);
+    return VG_LAUNCH_RC();
+}
+
 extern "C" int vg_rng_advance(uint64_t* rng, void* stream) {
     VG_CHECK_ARG(rng != nullptr, VG_EINVAL);
     hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, vg_stream(stream), (unsigned long long*)rng);
@@ -791,7 +829,30 @@ extern "C" int vg_kl_forward(const void* mulv, const float* lv_clamped, int B, i
                              int dtype, void* stream) {
     CHECK_DT();
     VG_CHECK_ARG(mulv && lv_clamped && out && B > 0 && L > 0 && MP >= 2 * L && divisor != 0.f, VG_EINVAL);
-    DISPATCH_DT(kl_kernel, dim3(1), dim3(1024), vg_stream(stream), mulv, lv_clamped, B, L, MP, divisor, out);
+    DISPATCH_DT(kl_kernel, dim3(1), dim3(1024), vg_stream(stream), mulv, lv_clamped, B, L, MP, divisor, out,
+                (const float*)nullptr, 0, 1.0, (float*)nullptr);
+    return VG_LAUNCH_RC();
+}
+
+extern "C" int vg_kl_forward_mse_final(const void* mulv, const float* lv_clamped, int B, int L, int MP, float divisor,
+                                       float* out, const float* mse_ws, int mse_nparts, int64_t mse_n, float* mse_loss,
+                                       int dtype, void* stream) {
+    CHECK_DT();
+    VG_CHECK_ARG(mulv && lv_clamped && out && B > 0 && L > 0 && MP >= 2 * L && divisor != 0.f, VG_EINVAL);
+    VG_CHECK_ARG(mse_ws && mse_loss && mse_nparts > 0 && mse_n > 0, VG_EINVAL);
+    DISPATCH_DT(kl_kernel, dim3(1), dim3(1024), vg_stream(stream), mulv, lv_clamped, B, L, MP, divisor, out, mse_ws,
+                mse_nparts, (double)mse_n, mse_loss);
+    return VG_LAUNCH_RC();
+}
+
+extern "C" int vg_mse_partial(const float* a, const float* b, int64_t n, float gscale, float* d_a, float* ws,
+                              int ws_capacity, int* nparts_out, void* stream) {
+    VG_CHECK_ARG(a && b && ws && nparts_out && n > 0 && ws_capacity >= 1, VG_EINVAL);
+    int blocks = blocks_for(n / 4 + 1, 1024);
+    if (blocks > ws_capacity) blocks = ws_capacity;
+    const float gcoef = (float)((double)gscale * 2.0 / (double)n);
+    hipLaunchKernelGGL(mse_partial_kernel, dim3(blocks), dim3(256), 0, vg_stream(stream), a, b, n, gcoef, d_a, ws);
+    *nparts_out = blocks;
     return VG_LAUNCH_RC();
 }
 

@@ -255,12 +255,14 @@ class Encoder(_EngineNet):
         self._engine = StackEngine(stages, self._dt, img_size[0], fp8_fprop=_is_fp8(dtype))
 
     # mulv-level API used by trainer.py (no mu/logvar split, no autograd)
-    def engine_forward(self, x_nchw, keep=True):
+    def engine_forward(self, x_nchw, keep=True, x_nhwc=None):
+        """x_nhwc: the same batch already in the engine's NHWC layout (the trainer converts it together with the
+        Discriminator's noisy copy in one pass)."""
         B, C, H, W = x_nchw.shape
         if H != self._img or W != self._img:
             raise RuntimeError(f"Encoder was built for {self._img}x{self._img} images, got {H}x{W} "
                                f"(mat1 and mat2 shapes cannot be multiplied)")
-        xh = ops.nchw_to_nhwc(x_nchw.contiguous(), G.padc(C, self._dt), self._dt)
+        xh = x_nhwc if x_nhwc is not None else ops.nchw_to_nhwc(x_nchw.contiguous(), G.padc(C, self._dt), self._dt)
         mulv, saved = self._engine.forward(xh, B, self.training, keep)
         return mulv.view(B, -1), saved
 

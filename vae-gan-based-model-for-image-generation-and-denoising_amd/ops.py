@@ -645,6 +645,24 @@ def nchw_to_nhwc(x, CP, dtype, eps=None, sigma=0.0, out=None):
     return y
 
 
+def nchw_to_nhwc_pair(x, CP, dtype, eps, sigma, out_noisy):
+    """(x as NHWC, x + sigma * eps as NHWC written into out_noisy) in ONE pass over x (vg_nchw_to_nhwc_pair), or None where
+    the four-pixel kernel does not apply.  eps: NCHW f32 noise tensor or a NoiseDraw."""
+    rng = isinstance(eps, NoiseDraw)
+    _need_cuda(x, None if rng else eps, out_noisy)
+    B, C, H, W = x.shape
+    if dtype != 1 or CP != 8 or C > 4 or (H * W) % 4 != 0:
+        return None
+    plain = empty_act((B, H, W, CP), dtype, x.device)
+    rc = L.load().vg_nchw_to_nhwc_pair(x.data_ptr(), None if rng else eps.data_ptr(), eps.state.data_ptr() if rng else None,
+                                       eps.draw if rng else 0, sigma, out_noisy.data_ptr(), plain.data_ptr(), B, C, H, W, CP,
+                                       dtype, L.stream_ptr())
+    if rc == L.VG_ENOSUP:
+        return None
+    L.check(rc, "vg_nchw_to_nhwc_pair")
+    return plain, out_noisy
+
+
 def gather_normalize_u8(images_u8, idx, out=None):
     """images_u8 [N,H,W,C] uint8 on the device, idx [B] int64 on the device -> [B,C,H,W] f32 in [-1,1]
     (ToTensor + Normalize(0.5,0.5), dataset_code.py:147-150)."""
@@ -745,9 +763,17 @@ def reparam_forward(mulv, eps, L_dim, ZP, dtype):
     return z, lvc
 
 
-def kl_forward(mulv, lvc, L_dim, divisor, dtype, out=None):
+def kl_forward(mulv, lvc, L_dim, divisor, dtype, out=None, mse=None):
+    """mse = (workspace, nparts, n, loss slot) from mse_forward_backward(..., defer_final=True): the MSE's final sum is
+    formed by this launch (vg_kl_forward_mse_final), same arithmetic as its own finalize launch."""
     B, MP = mulv.shape[0], mulv.shape[-1]
     out = out if out is not None else torch.empty(1, dtype=torch.float32, device=mulv.device)
+    if mse is not None:
+        ws, nparts, n, slot = mse
+        L.check(L.load().vg_kl_forward_mse_final(mulv.data_ptr(), lvc.data_ptr(), B, L_dim, MP, divisor, out.data_ptr(),
+                                                 ws.data_ptr(), nparts, n, slot.data_ptr(), dtype, L.stream_ptr()),
+                "vg_kl_forward_mse_final")
+        return out
     L.check(L.load().vg_kl_forward(mulv.data_ptr(), lvc.data_ptr(), B, L_dim, MP, divisor, out.data_ptr(), dtype,
                                    L.stream_ptr()), "vg_kl_forward")
     return out
@@ -840,11 +866,18 @@ def clamp_(flat, lo, hi):
     L.check(L.load().vg_clamp(flat.data_ptr(), flat.numel(), lo, hi, L.stream_ptr()), "vg_clamp")
 
 
-def mse_forward_backward(a, b, gscale, loss, want_grad):
+def mse_forward_backward(a, b, gscale, loss, want_grad, defer_final=False):
+    """defer_final=True: only the partial sums (+ gradient) are launched; returns (da, (ws, nparts, n, loss)) for
+    kl_forward(..., mse=...) to finish."""
     _need_cuda(a, b, loss)
     n = a.numel()
     da = torch.empty_like(a) if want_grad else None
     ws = WS.get("mse", 1024 * 4, a.device)
+    if defer_final:
+        npo = c_int(0)
+        L.check(L.load().vg_mse_partial(a.data_ptr(), b.data_ptr(), n, gscale, L.ptr(da), ws.data_ptr(), 1024, byref(npo),
+                                        L.stream_ptr()), "vg_mse_partial")
+        return da, (ws, npo.value, n, loss)
     L.check(L.load().vg_mse_forward_backward(a.data_ptr(), b.data_ptr(), n, gscale, loss.data_ptr(), L.ptr(da),
                                              ws.data_ptr(), 1024, L.stream_ptr()), "vg_mse_forward_backward")
     return da
@@ -856,9 +889,10 @@ def axpy(a, b, alpha, out=None):
     return out
 
 
-def step_prologue(noise, optimizers) -> None:
-    """Top of an iteration, one single-thread launch: noise.advance() (noise may be None) and the step counters / bias
-    corrections of `optimizers` (optim.Adam, at most 4) -- their step(prepared=True) then launches the update alone."""
+def step_prologue(noise, optimizers, zero=None) -> None:
+    """Top of an iteration, one single-thread launch: noise.advance() (noise may be None), the step counters / bias
+    corrections of `optimizers` (optim.Adam, at most 4) -- their step(prepared=True) then launches the update alone --
+    and, when given, the iteration's loss slots `zero` (f32, <= 64 elements) set to 0 (instead of a memset node)."""
     import ctypes
     n = len(optimizers)
     states = (ctypes.c_void_p * max(n, 1))(*[o.state_dev.data_ptr() for o in optimizers])
@@ -866,7 +900,23 @@ def step_prologue(noise, optimizers) -> None:
     b1 = (ctypes.c_double * max(n, 1))(*[o.betas[0] for o in optimizers])
     b2 = (ctypes.c_double * max(n, 1))(*[o.betas[1] for o in optimizers])
     L.check(L.load().vg_step_prologue(noise.state.data_ptr() if noise is not None else None, states, lr, b1, b2, n,
-                                      L.stream_ptr()), "vg_step_prologue")
+                                      L.ptr(zero), 0 if zero is None else zero.numel(), L.stream_ptr()), "vg_step_prologue")
+
+
+def adam_apply2(opt_a, opt_b) -> None:
+    """The prepared update of TWO optim.Adam instances in one launch (vg_adam_apply2); bit-identical to two adam_step(...,
+    prepared=True) launches."""
+    import ctypes
+    oo = (opt_a, opt_b)
+    arr = lambda f: (ctypes.c_void_p * 2)(*[f(o) for o in oo])       # noqa: E731
+    n = (ctypes.c_int64 * 2)(*[o.flat_p.numel() for o in oo])
+    b1 = (ctypes.c_double * 2)(*[o.betas[0] for o in oo])
+    b2 = (ctypes.c_double * 2)(*[o.betas[1] for o in oo])
+    eps = (ctypes.c_double * 2)(*[o.eps for o in oo])
+    gs = (ctypes.c_float * 2)(*[o.grad_scale for o in oo])
+    L.check(L.load().vg_adam_apply2(arr(lambda o: o.flat_p.data_ptr()), arr(lambda o: o.flat_g.data_ptr()),
+                                    arr(lambda o: o.exp_avg.data_ptr()), arr(lambda o: o.exp_avg_sq.data_ptr()), n, b1, b2,
+                                    eps, gs, arr(lambda o: o.state_dev.data_ptr()), L.stream_ptr()), "vg_adam_apply2")
 
 
 def launch_count() -> int:

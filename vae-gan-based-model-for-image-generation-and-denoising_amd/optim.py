@@ -121,6 +121,19 @@ class Adam:
         self.steps += 1
         bump_weights_epoch(self.params)
 
+    def step_pair(self, other: "Adam") -> None:
+        """self.step(prepared=True); other.step(prepared=True) as ONE launch (both optimizers prepared by this iteration's
+        ops.step_prologue); results are bit-identical to the two launches."""
+        for o in (self, other):
+            for p, off in zip(o.params, o.offsets):
+                g = p.grad
+                if g is None or g.data_ptr() != o.flat_g.data_ptr() + 4 * off:
+                    raise RuntimeError("step_pair needs every .grad homed in the optimizer's flat gradient buffer")
+        ops.adam_apply2(self, other)
+        for o in (self, other):
+            o.steps += 1
+            bump_weights_epoch(o.params)
+
     def state_dict(self):
         st = {}
         for i, (p, o) in enumerate(zip(self.params, self.offsets)):

@@ -54,6 +54,10 @@ class VAEGANTrainer:
         # noise counter + the three optimizers' step counters / bias corrections in ONE launch at the top of the iteration
         # (ops.step_prologue) instead of one per optimizer step; False: every step() prepares itself
         self.fuse_step_prologue = os.environ.get("VG_STEP_PROLOGUE", "1") != "0"
+        # round 4: four pairs of small launches merged (the Encoder's input conversion + the noisy real batch; the MSE's
+        # final sum + the KL term; the Encoder's + the Generator's Adam step; the loss slots' memset + the prologue) --
+        # bit-identical results; False restores the separate launches (A/B and test switch)
+        self.merge_small_launches = os.environ.get("VG_MERGE_SMALL", "1") != "0"
         self.reducer = reducer
         # sync_bn: BatchNorm statistics over the global batch of all ranks (ddp.py) -- an N-rank step then equals
         # the reference's single-process step on the concatenated batch.  Off: per-replica statistics.
@@ -102,6 +106,7 @@ class VAEGANTrainer:
         return (tuple(real.shape), float(self.alpha_kl * min(1.0, epoch / 50)), inject, self.E.training, self.G.training,
                 self.D.training, self.alpha_adv, self.sigma, self.real_label, self.fake_label, self.d_iters,
                 self.elide_dead_grads, self.group_d_passes, self.fuse_head_backward, self.fuse_step_prologue,
+                self.merge_small_launches,
                 id(self.reducer), self.sync_bn, opts,
                 None if self.noise is None or inject else self.noise.state.data_ptr())
 
@@ -196,25 +201,30 @@ class VAEGANTrainer:
         # one single-thread launch for everything that only counts: the noise iteration and the step counters / bias
         # corrections of the three Adam steps below (the Discriminator's second update prepares itself)
         prep = self.fuse_step_prologue and self.d_iters >= 1
+        # slots 0..4 are written (not accumulated) below when d_iters >= 2; with d_iters = 1 slot 4 (d_loss_2) is never
+        # written and with d_iters > 2 it holds the LAST iteration's loss -- zeroed so that it reads 0, not stale memory.
+        # With the prologue launch the zeroing rides on it (no memset node in the captured iteration).
+        losses = torch.empty(8, dtype=torch.float32, device=dev) if prep else ops.zeros_f32(8, dev)
         if prep:
-            ops.step_prologue(noise, [self.opt_D, self.opt_G, self.opt_E])
+            ops.step_prologue(noise, [self.opt_D, self.opt_G, self.opt_E], zero=losses)
         elif noise is not None:
             noise.advance()
-        # slots 0..4 are written (not accumulated) below when d_iters >= 2; with d_iters = 1 slot 4 (d_loss_2) is never
-        # written and with d_iters > 2 it holds the LAST iteration's loss -- zeroed so that it reads 0, not stale memory
-        losses = ops.zeros_f32(8, dev)
         sink = GradSink(direct=True)
 
         # ---- Encode / reparameterise / decode (:74-83) ----
-        mulv, ctxE = E.engine_forward(real)
-        ZP = G.padc(Gn.nz, dt)
-        z, lvc = ops.reparam_forward(mulv, eps_z, L, ZP, dt)
-        # ---- instance noise, drawn once per step (:91-92); produced directly in the layout D reads.  Both noisy
-        # batches live in one [2B] buffer so that a Discriminator iteration can run real+fake as ONE grouped pass
-        # (per-group BatchNorm statistics, running stats updated real-then-fake as the reference's two calls do).
+        # instance noise, drawn once per step (:91-92), produced directly in the layout D reads.  Both noisy batches live
+        # in one [2B] buffer so that a Discriminator iteration can run real+fake as ONE grouped pass (per-group BatchNorm
+        # statistics, running stats updated real-then-fake as the reference's two calls do).  The Encoder's input and the
+        # Discriminator's noisy real batch are the same images: one pass over `real` writes both (round 4).
         CP = G.padc(D.nc, dt)
         both = ops.empty_act((2 * B, real.shape[2], real.shape[3], CP), dt, dev)
-        real_noisy = ops.nchw_to_nhwc(real, CP, dt, eps=eps_real, sigma=self.sigma, out=both[:B])
+        pair = ops.nchw_to_nhwc_pair(real, CP, dt, eps_real, self.sigma, both[:B]) \
+            if (self.merge_small_launches and G.padc(real.shape[1], dt) == CP) else None
+        mulv, ctxE = E.engine_forward(real, x_nhwc=None if pair is None else pair[0])
+        ZP = G.padc(Gn.nz, dt)
+        z, lvc = ops.reparam_forward(mulv, eps_z, L, ZP, dt)
+        real_noisy = both[:B] if pair is not None else \
+            ops.nchw_to_nhwc(real, CP, dt, eps=eps_real, sigma=self.sigma, out=both[:B])
         recon_noisy = both[B:]
         if Gn.nc == D.nc and G.padc(Gn.nc, dt) == CP and Gn.fused_tail(B):
             # the last ConvTranspose2d's kernel applies Tanh and writes the NCHW image AND image + sigma*eps in D's layout
@@ -255,8 +265,13 @@ class VAEGANTrainer:
 
         # ---- Generator + VAE loss (:110-117) ----
         p_adv, c_adv = D.engine_forward(recon_noisy, B)
-        d_recon = ops.mse_forward_backward(recon, real, 1.0, losses[0:1], True)               # :113
-        ops.kl_forward(mulv, lvc, L, float(B), dt, out=losses[1:2])                           # :114
+        if self.merge_small_launches:
+            # :113-114: the MSE's final sum rides on the KL launch (same arithmetic as its own one-wave launch)
+            d_recon, mse_tail = ops.mse_forward_backward(recon, real, 1.0, losses[0:1], True, defer_final=True)
+            ops.kl_forward(mulv, lvc, L, float(B), dt, out=losses[1:2], mse=mse_tail)
+        else:
+            d_recon = ops.mse_forward_backward(recon, real, 1.0, losses[0:1], True)           # :113
+            ops.kl_forward(mulv, lvc, L, float(B), dt, out=losses[1:2])                       # :114
         dp_adv = None
         if not fused_head:
             dp_adv = ops.bce_forward_backward(p_adv, self.real_label, self.alpha_adv, losses[2:3], False, True)  # :115
@@ -274,8 +289,11 @@ class VAEGANTrainer:
         dmulv = ops.reparam_kl_backward(mulv, lvc, eps_z, dz, kl_w / B, L, dt)
         E._engine.backward(ctxE, dmulv.view(B, 1, 1, -1), False, sink, on_grads=self._grad_hook(self.opt_E, E))
         self._finish_reduce(self.opt_E, E, also_wait=(self.opt_G,))
-        self.opt_E.step(prepared=prep)
-        self.opt_G.step(prepared=prep)
+        if prep and self.merge_small_launches:
+            self.opt_E.step_pair(self.opt_G)                  # :134-135 in one launch (both prepared by the prologue)
+        else:
+            self.opt_E.step(prepared=prep)
+            self.opt_G.step(prepared=prep)
         self.losses = losses
         return losses
 
