@@ -18,7 +18,7 @@ What the engine stores in bf16 (engine.py / ops.py / csrc, dtype VG_BF16), i.e. 
             * the Encoder head's [mu | logvar] (mulv) and the latent z; the clamped logvar, p = sigmoid(.), the f32 NCHW
               reconstruction tanh(.) and all losses stay f32
   backward  * every data gradient dX written by a dgrad GEMM (the activation mask of a BatchNorm-less layer below is applied
-              BEFORE the rounding: one rounding of mask*dX), the Discriminator head's dX
+              to the ROUNDED tile and the product rounded again: q(slope * q(dX))), the Discriminator head's dX
             * every BatchNorm-backward output dY = a*dz - b*xhat - c (xhat and act' are re-derived from the STORED q(Y))
             * the gradient of the pre-tanh reconstruction q((d_mse + d_adv) * (1 - recon^2)), and d[mu | logvar]
             * weight / bias / gamma / beta gradients and the (sum dz, sum dz*xhat) reductions are f32: not rounded
@@ -183,10 +183,11 @@ class RefVAEGANbf16(R.RefVAEGAN):
             if n == len(convs) - 1:                                # head: Conv2d(C, 1, 4, 1, 0) + Sigmoid, f32 logit / p
                 return torch.sigmoid(F.conv2d(self.gq(a, f"dX:D.{n}"), w, None, stride=s, padding=p)).view(-1)
             if n == 0:
-                # no BatchNorm: LeakyReLU in the conv epilogue, only q(act(Y)) is stored; its backward is a mask applied
-                # to stage 1's dgrad tile BEFORE that tile is stored (one rounding of mask * dX)
+                # no BatchNorm: LeakyReLU in the conv epilogue, only q(act(Y)) is stored; its backward is a mask applied by
+                # stage 1's dgrad epilogue to its tile AFTER the tile's bf16 rounding (conv_gemm.hip mask_segment): the
+                # slope-multiplied elements are rounded twice, q(slope * q(dX))
                 Y = F.conv2d(a, w, None, stride=s, padding=p)
-                a = self.q(F.leaky_relu(self.gq(Y, "dX:D.1"), spec[i + 1][1]), f"A:D.{n}")
+                a = self.q(self.gq(F.leaky_relu(self.gq(Y, "dX:D.1"), spec[i + 1][1]), "dX:D.1"), f"A:D.{n}")
             else:
                 if n > 1:
                     a = self.gq(a, f"dX:D.{n}")

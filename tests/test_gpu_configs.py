@@ -17,6 +17,7 @@ import pytest
 import torch
 
 import vaegan_ref as R
+import vaegan_ref_bf16 as RB
 from _inputs import make_inputs
 
 import vaegan_amd as V
@@ -38,14 +39,19 @@ def oracle_grads(S, B, seed, double):
     return {f"{n}.{k}": st[k].grad.double() for n, st in (("E", o.E), ("G", o.G), ("D", o.D)) for k in R.trainable_keys(st)}
 
 
-# bf16 storage keeps 8 significant bits: every stored activation / gradient carries a relative rounding error of up to
-# 2^-9 = 2e-3.  At the seed-42 initial point the Discriminator's output is nearly the same for every sample, so each
-# BatchNorm backward (dx ~ dz - mean(dz) - xhat * mean(dz * xhat)) subtracts two almost equal quantities and amplifies
-# that rounding ~25x per BatchNorm layer it passes (the fp32 reference amplifies ITS 6e-8 rounding to 1e-3 on the same
-# tensors: cpu-fp32 column of tools/calibrate_r03.py).  Measured on MI355X, per tensor, relative Frobenius error against
-# the fp64 oracle: Discriminator 4e-3 (head) ... 9e-2 (first conv), Generator 4e-2 ... 2.0e-1 (G.main.0), Encoder
-# 1e-2 ... 1.6e-1.  Stated bf16 bounds: 3e-1 per tensor, and the direction (cosine) within 0.95 of the true gradient's.
-BF16_GRAD_TOL, BF16_GRAD_COS = 3e-1, 0.95
+# bf16 storage keeps 8 significant bits.  Round 4 replaced the argued explanation of round 3 by a measured one
+# (oracle/vaegan_ref_bf16.py: exact arithmetic + bf16 rounding at the engine's storage points; tools/bf16_ablation.py,
+# profiles/r04_bf16_ablation.txt): the 0.4 % ... 20 % distance of the bf16 gradients from the fp64 oracle at the seed-42
+# initial point is reproduced by that emulation tensor by tensor (G.main.0.weight 1.99e-1 against the engine's 2.00e-1),
+# it comes from the FORWARD storage roundings together (forward exact: 7e-3; weights / images / raw outputs / activations
+# exact one class at a time: 1.9e-1 ... 2.0e-1) and NOT from any stored gradient (backward exact: unchanged 2.1e-1; any
+# single dX / dY exact: unchanged) -- at initialisation the Discriminator's output is nearly the same for every sample, so
+# the generator-side gradient is a small difference of large terms that every forward perturbation moves.  Bounds: per
+# tensor the engine may be at most 1.5 x as far from fp64 as the emulation of the arithmetic it was asked to do (measured
+# <= 1.24 x, tools/calibrate_r04.py) -- or 4 x the CPU-fp32 oracle's own distance where that is larger --, with the absolute
+# backstop 3e-1 and the direction (cosine) within 0.95 of the true gradient's.  The kernel-level correctness bound of
+# the same iteration is tests/test_gpu_layerwise.py (every stage against exact arithmetic on its own stored inputs, <= 3e-4).
+BF16_GRAD_TOL, BF16_GRAD_COS, BF16_VS_EMULATION = 3e-1, 0.95, 1.5
 
 
 def test_bf16_gradients_of_the_benchmarked_configuration_replayed_graph_vs_fp64_oracle():
@@ -64,15 +70,20 @@ def test_bf16_gradients_of_the_benchmarked_configuration_replayed_graph_vs_fp64_
     hip = {f"{n}.{k}": p.grad.double().cpu() for n, m in (("E", e), ("G", g), ("D", d)) for k, p in m.named_parameters()}
     g32, g64 = oracle_grads(S, B, seed, False), oracle_grads(S, B, seed, True)
     assert sorted(hip) == sorted(g64)
+    em = RB.RefVAEGANbf16(img_size=S, seed=42, lr=0.0)
+    em.train_step(*make_inputs(B, S, seed), 60)
+    gem = {f"{n}.{k}": st[k].grad.double() for n, st in (("E", em.E), ("G", em.G), ("D", em.D)) for k in R.trainable_keys(st)}
     worst, report = 0.0, []
     for k, r in g64.items():
         if float(r.abs().max()) < 1e-6:
             # conv bias in front of BatchNorm: exactly zero in exact arithmetic, rounding noise in every implementation
             assert float(hip[k].abs().max()) < 1e-3, k
             continue
-        err, cal = frob(hip[k], r), frob(g32[k], r)
+        err, cal, emu = frob(hip[k], r), frob(g32[k], r), frob(gem[k], r)
         cos = float((hip[k] * r).sum() / (hip[k].norm() * r.norm()))
         report.append((err, cal, k))
+        assert err <= max(BF16_VS_EMULATION * emu, 4 * cal, 1e-3), \
+            f"{k}: bf16 engine {err:.2e} from fp64, the bf16-storage emulation of the same arithmetic only {emu:.2e}"
         worst = max(worst, err)
         assert cos >= BF16_GRAD_COS, f"{k}: bf16 gradient points {cos:.3f} (cosine) from the fp64 oracle's"
     report.sort(reverse=True)

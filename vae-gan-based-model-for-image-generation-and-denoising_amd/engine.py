@@ -171,6 +171,10 @@ class StackEngine:
         self._pack_key = None
         self._pack_ptrs = None
         self.pending_bn_ticks = 0           # num_batches_tracked increments not yet applied (flushed lazily)
+        # test instrumentation: a list -> backward() appends, per stage, the tensors each kernel group read and wrote
+        # (clones), so that a test can re-derive every stage's output from the engine's OWN stored inputs in exact
+        # arithmetic (tests/test_gpu_layerwise.py).  None (the default): nothing is recorded.
+        self.trace = None
         self.bn_sync = None                 # ddp.GradReducer -> BatchNorm statistics over all ranks (SyncBN mode)
 
     # ---- geometry (cached per batch size) -----------------------------------------------------
@@ -380,6 +384,9 @@ class StackEngine:
                 if keep:
                     ctx.append({"x": a, "Y": None, "Yshape": Yshape, "coeffs": None,
                                 "rows": B * st.hout * st.hout, "OC": OC})
+                if self.trace is not None:
+                    self.trace.append(dict(stage=i, what="fwd_tn", x=a.clone(), A=out.clone(), B=B,
+                                           noisy=None if (tail is None or tail.get("out_noisy") is None) else tail["out_noisy"].clone()))
                 a, a8 = out, None
                 continue
             gg, pk = self.spec(i, B, "fprop")
@@ -434,6 +441,9 @@ class StackEngine:
                 out, out8 = Y, None                         # activation (if any) already applied by the epilogue
             if keep:
                 ctx.append({"x": a, "Y": Y, "coeffs": coeffs, "rows": rows, "OC": OC})
+            if self.trace is not None:
+                self.trace.append(dict(stage=i, what="fwd", x=a.clone(), Y=Y.clone(), A=out.clone(), groups=groups, B=B,
+                                       coeffs=None if coeffs is None else coeffs.clone(), fused_act=fuse_act))
             a, a8 = out, out8
         if train and any(st.bn is not None for st in self.stages):
             self.pending_bn_ticks += groups
@@ -508,15 +518,25 @@ class StackEngine:
                 dY = ops.act_backward(Y, dA, st.act, st.slope, dt)
             else:
                 dY = dA                                     # no activation, or its backward was fused into the dgrad above
+            if self.trace is not None:
+                self.trace.append(dict(stage=i, what="bn_bwd", dA=dA.clone(), dY=dY.clone(), Y=None if Y is None else Y.clone(),
+                                       coeffs=None if c["coeffs"] is None else c["coeffs"].clone(), masked_in=masked))
             masked = False
             if param_grads:
+                acc_before = st.conv.weight.grad is not None and not getattr(st.conv.weight, "_vg_fresh", False)
                 self._param_grads(i, st, c, dY, B, rows, OC, sink)
                 if on_grads is not None:
                     on_grads(i)
+                if self.trace is not None:
+                    self.trace.append(dict(stage=i, what="wgrad", dY=dY.clone(), x=c["x"].clone(), acc=acc_before,
+                                           gw=None if st.conv.weight.grad is None else st.conv.weight.grad.detach().clone(),
+                                           gw2=None if (st.conv2 is None or st.conv2.weight.grad is None) else st.conv2.weight.grad.detach().clone()))
             if want_dx and self.tn(i, B, "dgrad") is not None:
                 tnsp, _ = self.tn(i, B, "dgrad")            # image gradient below a narrow first Conv2d (edge layer)
                 dX, _ = ops.tnconv(tnsp, dY, packs[i]["tn_dgrad"], alg=st.alg(B, dt))
                 dA = dX.view(c["x"].shape)
+                if self.trace is not None:
+                    self.trace.append(dict(stage=i, what="dgrad", dY=dY.clone(), dX=dA.clone(), mask=None))
             elif want_dx:
                 ggd, _ = self.spec(i, B, "dgrad")
                 mask = None
@@ -529,6 +549,9 @@ class StackEngine:
                         masked = True
                 dX, _, _ = ops.gather_gemm(ggd, dY, packs[i]["dgrad"], dt, alg=st.alg(B, dt), mask=mask)
                 dA = dX.view(c["x"].shape)
+                if self.trace is not None:
+                    self.trace.append(dict(stage=i, what="dgrad", dY=dY.clone(), dX=dA.clone(),
+                                           mask=None if mask is None else (mask[0].clone(), mask[1], mask[2])))
             else:
                 dA = None
         return dA
