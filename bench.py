@@ -34,13 +34,13 @@ PEAK = {"fp32": 157.3, "bf16": 2500.0, "fp8": 5000.0}          # dense MFMA TFLO
 # HBM-side bytes per gather-GEMM launch from the rocprofv3 PMC passes committed under profiles/ (separate
 # --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command; FETCH_SIZE doubled per the gfx950 correction of
 # MI355X_MICROARCH.md section HBM, counters in KiB): measured offline, NOT re-measured by this run.
-def pmc_traffic(dtype):
-    """(bytes per gather-GEMM launch, source file) from the newest committed PMC summary
+def pmc_traffic(dtype, family="gather_gemm"):
+    """(HBM-side bytes per launch of `family`, source file) from the newest committed PMC summary
     (profiles/rNN_<dtype>_pmc_traffic.json): measured offline by separate rocprofv3 --pmc passes, not by this run."""
     for rnd in ("r04", "r03", "r02", "r01"):
         f = os.path.join(ROOT, "profiles", f"{rnd}_{dtype}_pmc_traffic.json")
         try:
-            return round(json.load(open(f))["families"]["gather_gemm"]["hbm_bytes_per_launch"]), os.path.relpath(f, ROOT)
+            return round(json.load(open(f))["families"][family]["hbm_bytes_per_launch"]), os.path.relpath(f, ROOT)
         except Exception:
             continue
     return None, None
@@ -459,10 +459,14 @@ def main():
     roofline_edge = None
     if ed["launches"]:
         gbs = ed["bytes"] / (ed["ms"] * 1e-3) / 1e9
+        etraffic, esrc = pmc_traffic(args.dtype, "edge")
         roofline_edge = {"bound": "hbm", "kernel": "edge layers: tnconv_kernel (narrow-N transposed conv, GEMM + col2im), "
                                                    "ggn_kernel (narrow-K direct conv)",
                          "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                         "traffic": None, "launches_per_step": ed["launches"] // args.steps,
+                         "traffic": etraffic if (S, B) == (64, 128) else None,
+                         "traffic_source": (f"{esrc}: separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (FETCH_SIZE "
+                                            f"doubled), measured offline" if (S, B) == (64, 128) and esrc else None),
+                         "launches_per_step": ed["launches"] // args.steps,
                          "avg_launch_us": round(ed["ms"] * 1e3 / ed["launches"], 2),
                          "alg_mbytes_per_launch": round(ed["bytes"] / ed["launches"] / 1e6, 2),
                          "share_of_step": round(ed["ms"] / args.steps / ms, 3)}

@@ -218,6 +218,28 @@ def test_bounded_bucket_plans_tile_the_buffer_for_locally_reordered_layouts():
             assert [ev for _, _, ev in plan] == sorted((ev for _, _, ev in plan), reverse=True)
 
 
+def test_inline_bucket_plans_of_the_three_networks_at_S64():
+    """Buckets when the collectives are captured inside the hipGraph (ddp.INLINE_*: 2 MB, <= 4 per optimizer): D leaves
+    {head + last conv} early and waits for {the first three layers: 2.6 MB} only; G in four pieces; E in one."""
+    ddp = importlib.import_module(PKG + ".ddp")
+    dsz = [3072, 131072, 128, 128, 524288, 256, 256, 2097152, 512, 512, 8192]
+    drd = [0, 1, 1, 1, 2, 2, 2, 3, 3, 3, 4]
+    gsz = [1638400, 1024, 1024, 8388608, 512, 512, 2097152, 256, 256, 524288, 128, 128, 131072, 64, 64, 1728]
+    grd = [0, 0, 0, 1, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 4, 5]
+    esz = [1536, 32, 32, 32, 32768, 64, 64, 64, 131072, 128, 128, 128, 524288, 256, 256, 256, 102400, 100, 102400, 100]
+    erd = [0] * 4 + [1] * 4 + [2] * 4 + [3] * 4 + [4] * 4
+    got = {}
+    for name, sizes, ready in (("D", dsz, drd), ("G", gsz, grd), ("E", esz, erd)):
+        offs, total = _layout(sizes)
+        plan = ddp.plan_buckets(offs, sizes, ready, total, ddp.INLINE_BUCKET_BYTES, ddp.INLINE_MAX_BUCKETS)
+        covered = sorted((lo, hi) for lo, hi, _ in plan)
+        assert covered[0][0] == 0 and covered[-1][1] == total and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+        got[name] = [(round((hi - lo) * 4 / 1e6, 1), ev) for lo, hi, ev in plan]
+    assert [ev for _, ev in got["D"]] == [3, 0] and got["D"][0][0] > 8.0 and got["D"][1][0] < 3.0, got["D"]
+    assert [ev for _, ev in got["G"]] == [3, 2, 1, 0], got["G"]
+    assert len(got["E"]) in (1, 2), got["E"]
+
+
 def test_reducer_requires_process_group():
     ddp = importlib.import_module(PKG + ".ddp")
     with pytest.raises(RuntimeError, match="process group"):

@@ -38,6 +38,12 @@ DEFAULT_BUCKET_BYTES = 8 << 20
 
 
 DEFAULT_MAX_BUCKETS = 2
+# Collectives captured INSIDE the hipGraph (round 4, RCCL): a bucket launch is a fork / join inside the graph, not a graph
+# cut, so finer buckets cost nothing on the compute stream and leave less of each network's all-reduce exposed: the
+# Discriminator's {head + last conv: 8.4 MB} leaves while its first three layers are still in their backward pass and only
+# {2.6 MB} is waited for before its Adam step (twice per iteration); the Generator goes in four pieces.
+INLINE_BUCKET_BYTES = 2 << 20
+INLINE_MAX_BUCKETS = 4
 
 
 def plan_buckets(offsets: Sequence[int], numels: Sequence[int], ready: Sequence[int], total: int,
@@ -87,14 +93,12 @@ def plan_buckets(offsets: Sequence[int], numels: Sequence[int], ready: Sequence[
 
 
 class GradReducer:
-    def __init__(self, process_group=None, bucket_bytes: int = DEFAULT_BUCKET_BYTES, max_buckets: int = DEFAULT_MAX_BUCKETS):
+    def __init__(self, process_group=None, bucket_bytes: int = None, max_buckets: int = None):
         if not dist.is_available() or not dist.is_initialized():
             raise RuntimeError("GradReducer needs an initialised torch.distributed process group "
                                "(backend 'nccl' = RCCL on the MI355X node, 'gloo' for CPU tests)")
         self.group = process_group
         self.world = dist.get_world_size(process_group)
-        self.bucket_bytes = int(bucket_bytes)
-        self.max_buckets = int(max_buckets)          # per optimizer; every bucket is one hipGraph cut (0: no bound)
         self._pending: Dict[int, list] = {}          # id(opt) -> [Work, ...]
         self._buckets: Dict[int, List[Tuple[int, int, int]]] = {}
         self.bytes_reduced = 0
@@ -109,6 +113,11 @@ class GradReducer:
         except Exception:
             backend = ""
         self.capturable = backend == "nccl" and os.environ.get("VAEGAN_DDP_CAPTURE", "1") != "0"
+        # per optimizer; in the segmented form every bucket is one hipGraph cut (0: no bound)
+        self.bucket_bytes = int(bucket_bytes if bucket_bytes is not None else
+                                (INLINE_BUCKET_BYTES if self.capturable else DEFAULT_BUCKET_BYTES))
+        self.max_buckets = int(max_buckets if max_buckets is not None else
+                               (INLINE_MAX_BUCKETS if self.capturable else DEFAULT_MAX_BUCKETS))
 
     def attach(self, *optimizers) -> None:
         """Fold the 1/world_size average into each optimizer's fused step."""
