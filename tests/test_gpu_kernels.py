@@ -127,6 +127,39 @@ def test_conv_transpose2d_fprop_dgrad_wgrad(ops, dtype, B, H, Cin, Cout, k, s, p
     close(dW.double().cpu(), dw_ref, dtype, f32=(1e-4, 2e-5), bf16=(3e-2, 3e-2))
 
 
+@pytest.mark.parametrize("B,H,Cin,Cout", [(64, 4, 1024, 512), (128, 4, 1024, 512), (128, 4, 512, 256), (96, 4, 512, 256)])
+def test_few_row_long_k_data_gradient_on_128x128_tiles_with_dma_k_slices(ops, vg_switch, B, H, Cin, Cout):
+    """Round 4: the data gradient of a deep ConvTranspose2d (gan_code.py:25-28; few rows, K = 16 * Cout) on 128 x 128
+    tiles whose K dimension is cut into slices that run on the LDS-DMA ring (VG_SPLITK_BIGK=1: conv_gemm.hip bigk_split_ok,
+    gg_kernel<.., SPLITK, DMA>), against the 64 x 64 tiles it replaces and against torch in fp64 on the same bf16
+    operands.  (128, 4, 1024, 512) is the Generator's stage-1 data gradient at the benchmark size."""
+    dtype, k, s, p = G.BF16, 4, 2, 1
+    g = torch.Generator().manual_seed(B + Cin)
+    x = _q(torch.randn(B, Cin, H, H, generator=g), dtype).requires_grad_(True)
+    w = torch.randn(Cin, Cout, k, k, generator=g) * 0.05
+    wq = _q(w, dtype)
+    y_ref = F.conv_transpose2d(x, wq, None, stride=s, padding=p)
+    dy = _q(torch.randn(y_ref.shape, generator=g), dtype)
+    (dx_ref,) = torch.autograd.grad(y_ref, x, dy)
+    gg, pk = G.convT_dgrad(B, H, H, Cin, Cout, k, s, p, dtype)
+    Wd = ops.pack_weights(pk, w.to(DEV), dtype)
+    DY = _dev(to_nhwc(dy, gg.IC), dtype, ops)
+    out = {}
+    for mode in ("0", "1"):
+        vg_switch("VG_SPLITK_BIGK", mode)
+        n0 = ops.launch_count()
+        DX, _, _ = ops.gather_gemm(gg, DY, Wd, dtype)
+        out[mode] = (DX.clone(), ops.launch_count() - n0)
+    torch.cuda.synchronize()
+    expect_split = (B * H * H) % 128 == 0 and (B * H * H // 128) * (Cin // 128) >= 64
+    if expect_split:
+        assert out["1"][1] == 2                                               # main launch + slab reduce
+    for mode in ("0", "1"):
+        close(from_nhwc(out[mode][0].double().cpu(), Cin), dx_ref, dtype)
+    d = (out["1"][0].float() - out["0"][0].float()).abs()
+    assert float((d > 0).float().mean()) < 2e-3                               # same sums, another order: rare one-ulp flips
+
+
 @pytest.mark.parametrize("dtype", [G.F32, G.BF16])
 def test_linear_fused_heads(ops, dtype):
     B, Hf, C, N = 8, 2, 256, 200

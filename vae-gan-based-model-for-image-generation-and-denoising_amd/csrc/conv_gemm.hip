@@ -404,16 +404,19 @@ __global__ __launch_bounds__(256) void gg_kernel(const vg_gg_desc d, const int k
         // bounds test and the 64-bit source pointer are computed ONCE PER TAP; inside a tap each lane's pointer just
         // advances by 64 bytes per chunk (0 for lanes parked on the zero page).  The ablated build showed the
         // per-stage address generation, not the MFMAs, was the critical path of this kernel.
-        const bool fast = (upt % 4) == 0 && s_begin == 0;
+        // (round 4: also for a K slice that starts inside the operand -- split-K launches used to fall back to the
+        // per-stage address generation AND to register staging; the slice's first tap is entered mid-way: tap_chunk0)
+        const bool fast = (upt % 4) == 0;
         const int nct = upt >> 2;                                      // chunks per tap
-        int tap_chunk = 0;                                             // wave-uniform
+        int tap_chunk = fast ? (ld_cu >> 2) : 0;                       // wave-uniform (ld_cu - q is a multiple of 4)
+        bool tap_entered = false;                                      // the first tap of the slice still needs its addresses
         const unsigned char* a_cur[AP];
         uint32_t a_stride[AP];
         const unsigned char* b_cur[BP];
         uint32_t b_stride[BP];
 #pragma unroll
         for (int j = 0; j < BP; ++j) {
-            b_cur[j] = b_ok[j] ? b_ptr[j] : reinterpret_cast<const unsigned char*>(d.zeros);
+            b_cur[j] = b_ok[j] ? b_ptr[j] + ld_koff : reinterpret_cast<const unsigned char*>(d.zeros);
             b_stride[j] = b_ok[j] ? 64u : 0u;
         }
         auto issue_stage_fast = [&](int buf) {
@@ -421,7 +424,8 @@ __global__ __launch_bounds__(256) void gg_kernel(const vg_gg_desc d, const int k
             for (int c = 0; c < KCH; ++c) {
                 unsigned char* sa = smem + buf * STAGE + c * CHB;
                 unsigned char* sb = sa + BM * 64;
-                if (tap_chunk == 0) {                                  // new filter tap: the only expensive part
+                if (tap_chunk == 0 || !tap_entered) {                  // new filter tap: the only expensive part
+                    tap_entered = true;
                     const int dy = d.DY * ld_ta, dx = d.DX * ld_tb;
                     const int dpix = dy * d.IW + dx;
                     const bool tap_ok = ld_t < ntap;
@@ -429,7 +433,7 @@ __global__ __launch_bounds__(256) void gg_kernel(const vg_gg_desc d, const int k
                     for (int i = 0; i < AP; ++i) {
                         const bool ok = tap_ok && (unsigned)(a_iy[i] + dy) < (unsigned)d.IH &&
                                         (unsigned)(a_ix[i] + dx) < (unsigned)d.IW;
-                        a_cur[i] = ok ? Xb + ((uint32_t)(a_pix[i] + dpix) * pix_bytes + (uint32_t)q * 16u)
+                        a_cur[i] = ok ? Xb + ((uint32_t)(a_pix[i] + dpix) * pix_bytes + (uint32_t)q * 16u + (uint32_t)tap_chunk * 64u)
                                       : reinterpret_cast<const unsigned char*>(d.zeros);
                         a_stride[i] = ok ? 64u : 0u;
                     }
@@ -693,6 +697,20 @@ inline int patch256_min() { return vg_sw().patch256_min; }
 // 256 x 64: G4 forward 63.9 -> 63.0 us, D1 data gradient 30.9 -> 28.4 (2B) and 17.8 -> 15.9 (B)
 inline int patch256x64_min() { return vg_sw().patch256x64_min; }
 
+// Few rows, wide N, long K, nothing in the epilogue that needs final values (the data gradient of the Generator's second
+// ConvTranspose2d: M = B * 16 = 2048 rows, N = 1024, K = 8192 at S = 64): on 64 x 64 tiles every workgroup re-reads 64 weight
+// rows for only 64 data rows (32 FLOP per operand byte: 75 us, the least efficient launch of the step); 128 x 128 tiles halve
+// the operand bytes but offer 128 workgroups -- with the K dimension cut into slices on the LDS-DMA ring they offer 512.
+inline bool bigk_split_ok(const vg_gg_desc* d, bool bf16) {
+    if (!bf16 || vg_sw().splitk_bigk == 0 || !use_dma() || d->zeros == nullptr) return false;
+    const int M = d->B * d->GH * d->GW;
+    const bool flat = d->nphase == 1 && d->OSY == 1 && d->OSX == 1 && d->GH == d->OH && d->GW == d->OW;
+    if (!flat || d->stats != nullptr || d->act != VG_ACT_NONE || d->mask_x != nullptr) return false;
+    const int t128 = tiles_of(M, d->N, 128, 128);
+    const int nstages = (d->Kp * 2) / 128;                        // 2 chunks of 64 bytes per stage
+    return d->N >= 256 && M % 128 == 0 && t128 >= 64 && t128 <= 256 && nstages >= 32;      // (32 tiles -- S = 256, B = 32 -- measured slower: 3.62 -> 3.64 ms)
+}
+
 inline TileCfg pick_tile(const vg_gg_desc* d, bool bf16 = false, bool fp8 = false) {
     const int M = d->B * d->GH * d->GW;
     const int N = d->N;
@@ -721,6 +739,7 @@ inline TileCfg pick_tile(const vg_gg_desc* d, bool bf16 = false, bool fp8 = fals
         tiles_of(M, N, 256, 128) * ph >= patch256_min() && patch_geometry(d, 256, &pg))
         return {256, 128};
     if (N > 64 && tiles_of(M, N, 128, 128) * ph >= need) return {128, 128};
+    if (bigk_split_ok(d, bf16)) return {128, 128};               // few rows, long K: 128 x 128 tiles + split-K (plan_splitk)
     if (tiles_of(M, N, 128, 64) * ph >= need) return {128, 64};
     return {64, 64};
 }
@@ -762,10 +781,12 @@ inline SplitK plan_splitk(const vg_gg_desc* d, int dtype, TileCfg t) {
     const int gx = (M + t.bm - 1) / t.bm, gy = (d->N + t.bn - 1) / t.bn;
     const int tiles = gx * gy;
     const int max_tiles = vg_sw().splitk_max_tiles;
-    if (tiles > max_tiles || nstages < 16) return r;
+    const bool bigk = t.bm == 128 && t.bn == 128 && bigk_split_ok(d, dtype == VG_BF16);
+    if ((tiles > max_tiles && !bigk) || nstages < 16) return r;
     // aim at ~4 workgroups per CU, at most 64 splits (the Encoder's Linear layers -- 4 tiles, K = 50 176 at S = 256 -- are at
-    // their best there; more splits only add partial traffic), at least 4 stages per split
-    int ks = vg_sw().splitk_wgs / tiles;
+    // their best there; more splits only add partial traffic), at least 4 stages per split.  The big-K case aims at 2
+    // workgroups per CU: its f32 partials are the price (128 tiles x 64 KB per slice)
+    int ks = (bigk ? 512 : vg_sw().splitk_wgs) / tiles;
     if (ks > 64) ks = 64;
     if (ks > nstages / 4) ks = nstages / 4;
     if (ks < 2) return r;
@@ -803,7 +824,15 @@ int launch(const vg_gg_desc* d, hipStream_t s, SplitK sk) {
         else vg_launch_timed(3, gg_kernel<DT, BM, BN, WM, WN, false, false>, grid, dim3(256), 0, s, *d, one, nstages_all);
         return VG_LAUNCH_RC();
     } else if (split) {
-        vg_launch_timed(0, gg_kernel<DT, BM, BN, WM, WN, true, false>, grid, dim3(256), 0, s, *d, sk.ksplit, sk.sps);
+        bool launched = false;
+        if constexpr (CAN_DMA && BM >= 128) {                  // round 4: K slices on the LDS-DMA ring too (128-row tiles)
+            if (dma) {
+                vg_launch_timed(0, gg_kernel<DT, BM, BN, WM, WN, true, true>, grid, dim3(256), 0, s, *d, sk.ksplit, sk.sps);
+                launched = true;
+            }
+        }
+        if (!launched)
+            vg_launch_timed(0, gg_kernel<DT, BM, BN, WM, WN, true, false>, grid, dim3(256), 0, s, *d, sk.ksplit, sk.sps);
     } else if constexpr (CAN_DMA) {
         if (dma) vg_launch_timed(0, gg_kernel<DT, BM, BN, WM, WN, false, true>, grid, dim3(256), 0, s, *d, one, nstages_all);
         else vg_launch_timed(0, gg_kernel<DT, BM, BN, WM, WN, false, false>, grid, dim3(256), 0, s, *d, one, nstages_all);

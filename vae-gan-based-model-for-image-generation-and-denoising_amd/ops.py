@@ -311,6 +311,7 @@ def gather_gemm(g: GGSpec, X: torch.Tensor, Wp: torch.Tensor, dtype: int, bias: 
     stats, nparts = None, 0
     if want_stats:
         probe = _gg_desc(g, X, Wp, Y, bias, None, 0)
+        probe.stats = X.data_ptr()           # the tile choice of the launch below, which emits statistics (query only)
         nparts = lib.vg_gather_gemm_nparts(byref(probe), dtype)
         if nparts < 0:
             L.check(nparts, "vg_gather_gemm_nparts")
@@ -438,6 +439,7 @@ def wgrad(wg: WGSpec, P: torch.Tensor, Q: torch.Tensor, dW: torch.Tensor, accumu
 def gather_gemm_tile_m(g: GGSpec, X, Wp, dtype: int) -> int:
     """M edge of the tile the launcher will pick = rows covered by one BatchNorm statistics slab."""
     probe = _gg_desc(g, X, Wp, X, None, None, 0)
+    probe.stats = X.data_ptr()               # a launch that emits statistics (never dereferenced by the query): its tile choice
     r = L.load().vg_gather_gemm_tile_m(byref(probe), dtype)
     if r < 0:
         L.check(r, "vg_gather_gemm_tile_m")
