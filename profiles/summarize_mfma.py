@@ -71,8 +71,11 @@ def main():
         b = json.loads(open(sys.argv[3]).read().strip().splitlines()[-1])
         r = b["roofline"]
         flop = r["alg_gflop_per_launch"] * 1e9 * out["families"]["gather_gemm"]["launches"]
-        out["families"]["gather_gemm"]["alg_flop_cycles"] = flop / 1024.0
-        out["families"]["gather_gemm"]["busy_cycles_over_alg_cycles"] = out["families"]["gather_gemm"]["mfma_busy_cycles"] / (flop / 1024.0)
+        # FLOP per cycle and SIMD: v_mfma_f32_16x16x32_bf16 = 16 384 FLOP in 16 cycles; v_mfma_f32_16x16x4_f32 = 2 048 in 32
+        per_cycle = 64.0 if "fp32" in tag else 1024.0
+        out["flop_per_cycle_and_simd"] = per_cycle
+        out["families"]["gather_gemm"]["alg_flop_cycles"] = flop / per_cycle
+        out["families"]["gather_gemm"]["busy_cycles_over_alg_cycles"] = out["families"]["gather_gemm"]["mfma_busy_cycles"] / (flop / per_cycle)
     json.dump(out, open(os.path.join(here, f"{tag}_mfma_busy.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
 

@@ -160,6 +160,51 @@ def test_few_row_long_k_data_gradient_on_128x128_tiles_with_dma_k_slices(ops, vg
     assert float((d > 0).float().mean()) < 2e-3                               # same sums, another order: rare one-ulp flips
 
 
+@pytest.mark.parametrize("kind,B,H,Cin,Cout,k,s,p", [("conv", 128, 8, 256, 512, 4, 2, 1), ("conv", 128, 6, 128, 256, 4, 2, 0),
+                                                      ("conv", 32, 14, 64, 128, 4, 2, 0), ("convT", 32, 4, 1024, 512, 4, 2, 1),
+                                                      ("convT", 16, 8, 512, 256, 4, 2, 1), ("conv", 37, 8, 256, 512, 4, 2, 1)])
+def test_split_k_with_batchnorm_statistics_and_subpixel_phases(ops, vg_switch, kind, B, H, Cin, Cout, k, s, p):
+    """Round 4: small-M forward launches (64 x 64 tiles, <= one workgroup per CU) cut along K -- also with sub-pixel phases
+    (ConvTranspose2d) and with the BatchNorm partial sums, which the slab reduce forms (splitk_reduce2_kernel) -- against the
+    un-split launch (VG_SPLITK_GENERAL=0) and torch in fp64 on the same bf16 operands: outputs, bias, statistics slabs
+    (same slab count), zero padding channels.  (128, 8, 256, 512) is the Discriminator's last conv at B = 128."""
+    dtype = G.BF16
+    g = torch.Generator().manual_seed(B * 3 + Cin)
+    x = _q(torch.randn(B, Cin, H, H, generator=g), dtype)
+    if kind == "conv":
+        w = torch.randn(Cout, Cin, k, k, generator=g) * 0.05
+        b = torch.randn(Cout, generator=g)
+        y_ref = F.conv2d(x, _q(w, dtype), b.double(), stride=s, padding=p)
+        gg, pk = G.conv_fprop(B, H, H, Cin, Cout, k, s, p, dtype)
+    else:
+        w = torch.randn(Cin, Cout, k, k, generator=g) * 0.05
+        b = None
+        y_ref = F.conv_transpose2d(x, _q(w, dtype), None, stride=s, padding=p)
+        gg, pk = G.convT_fprop(B, H, H, Cin, Cout, k, s, p, dtype)
+    Wp = ops.pack_weights(pk, w.to(DEV), dtype)
+    X = _dev(to_nhwc(x, gg.IC), dtype, ops)
+    out = {}
+    for mode in ("0", "1"):
+        vg_switch("VG_SPLITK_GENERAL", mode)                 # (opt-in: off by default)
+        n0 = ops.launch_count()
+        Y, stats, nparts = ops.gather_gemm(gg, X, Wp, dtype, bias=None if b is None else b.to(DEV), want_stats=True)
+        out[mode] = (Y.clone(), stats[: nparts * 2 * Cout].clone().view(nparts, 2, Cout), nparts, ops.launch_count() - n0)
+    torch.cuda.synchronize()
+    assert out["0"][3] == 1 and out["1"][3] == 2 and out["0"][2] == out["1"][2]      # split: main + slab reduce; same slab rows
+    OH = y_ref.shape[-1]
+    for mode in ("0", "1"):
+        Yv = out[mode][0].view(B, OH, OH, -1)
+        close(from_nhwc(Yv.double().cpu(), Cout), y_ref, dtype)
+        assert (Yv[..., Cout:] == 0).all()
+        st = out[mode][1].double().sum(0).cpu()
+        torch.testing.assert_close(st[0], y_ref.sum((0, 2, 3)), rtol=1e-3, atol=3e-1)
+        torch.testing.assert_close(st[1], (y_ref ** 2).sum((0, 2, 3)), rtol=3e-2, atol=1e-2)
+    # slab by slab: the same rows feed the same slab in both forms
+    torch.testing.assert_close(out["1"][1], out["0"][1], rtol=2e-3, atol=2e-2)
+    d = (out["1"][0].float() - out["0"][0].float()).abs()
+    assert float((d > 0).float().mean()) < 2e-3
+
+
 @pytest.mark.parametrize("dtype", [G.F32, G.BF16])
 def test_linear_fused_heads(ops, dtype):
     B, Hf, C, N = 8, 2, 256, 200

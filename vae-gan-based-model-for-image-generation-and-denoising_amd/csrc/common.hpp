@@ -160,6 +160,7 @@ struct VgSwitches {
     int patch256_min;      // VG_PATCH256_MIN      256: least number of 256 x 128 tiles for the 8-wave patch kernel
     int patch256x64_min;   // VG_PATCH256X64_MIN   512: same for the 256 x 64 tile
     int splitk_max_tiles;  // VG_SPLITK_MAX_TILES  128: most output tiles for which the gather-GEMM splits K
+    int splitk_general;    // VG_SPLITK_GENERAL    0: (1: split K also for 64 x 64-tile launches with sub-pixel phases and / or BatchNorm statistics -- measured: the slab reduces cost more than the main kernels gain)
     int splitk_bigk;       // VG_SPLITK_BIGK       1: few-row / long-K data gradients on 128 x 128 tiles with K slices (0: 64 x 64 tiles)
     int splitk_wgs;        // VG_SPLITK_WGS        1024: workgroups a split-K launch aims at (tiles x splits; at most 64 splits)
     int gg_nmajor;         // VG_GG_NMAJOR         1: XCD-major over n tiles where the weights are the larger operand (2: always)

@@ -124,8 +124,9 @@ __global__ __launch_bounds__(256) void gg_kernel(const vg_gg_desc d, const int k
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int phase = ksplit > 1 ? 0 : blockIdx.z;          // split-K launches are single-phase: z = K slice
-    const int kz = ksplit > 1 ? blockIdx.z : 0;
+    // split-K launches: z = phase * ksplit + K slice (round 4: the sub-pixel phases of the transposed forms split too)
+    const int phase = ksplit > 1 ? (int)blockIdx.z / ksplit : (int)blockIdx.z;
+    const int kz = ksplit > 1 ? (int)blockIdx.z - phase * ksplit : 0;
     // XCD-aware tile order (cdna_hip_programming.md T1): workgroups are dealt round-robin over the 8 XCDs, each
     // with a private L2.  The launch is 1-D in (m tile, n tile); id -> (xcd = id % 8, slot = id / 8) and the slots
     // of one XCD walk ALL n tiles of an m tile before moving on, so the gathered A rows of an m tile are fetched
@@ -509,7 +510,7 @@ __global__ __launch_bounds__(256) void gg_kernel(const vg_gg_desc d, const int k
     if constexpr (SPLITK) {
         // split-K: raw f32 partial tile -> workspace slab [kz][Mpad][Npad]; bias/convert happen in the reduce kernel
         const int Npad = ((d.N + BN - 1) / BN) * BN;
-        float* slab = d.ws + ((int64_t)kz * m_tiles_ * BM + m0) * Npad + n0;
+        float* slab = d.ws + ((int64_t)(phase * ksplit + kz) * m_tiles_ * BM + m0) * Npad + n0;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -673,6 +674,94 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
+// Slab reduce of the general split-K launch (round 4): one workgroup per (tile of bm rows, 64 columns, phase).  Sums the K
+// slices in fixed order, adds the bias, forms the tile's BatchNorm partial sums (from the f32 values, valid output pixels only:
+// what the un-split epilogue does) into the same slab row stats[(phase * m_tiles + tile) * 2 + {0,1}][N], and writes the
+// output pixel through the phase's sub-pixel mapping as 16-byte channel runs.  ws: [phase][slice][Mpad][Npad] f32.
+template <int DT>
+__global__ __launch_bounds__(256) void splitk_reduce2_kernel(const vg_gg_desc d, const int ksplit, const int bm, const int Mpad,
+                                                             const int Npad) {
+    constexpr int VE = 16 / ElemT<DT>::size;                  // elements per 16-byte run: 4 (f32) / 8 (bf16)
+    constexpr int LPR = 64 / VE;                              // lanes per 64-column row: 16 / 8
+    constexpr int RPP = 256 / LPR;                            // rows per pass: 16 / 32
+    __shared__ float red[2][RPP][64];
+    const int tid = threadIdx.x;
+    const int phase = blockIdx.z;
+    const int m0 = blockIdx.x * bm, n0 = blockIdx.y * 64;
+    const int M = d.B * d.GH * d.GW, GHW = d.GH * d.GW;
+    const int rl = tid / LPR, cv = (tid % LPR) * VE;
+    const bool flat = (d.nphase == 1 && d.OSY == 1 && d.OSX == 1 && d.GH == d.OH && d.GW == d.OW);
+    const int64_t kstride = (int64_t)Mpad * Npad;
+    const float* base = d.ws + (int64_t)phase * ksplit * kstride;
+    float s1[VE], s2[VE], bv[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+        s1[e] = 0.f; s2[e] = 0.f;
+        const int n = n0 + cv + e;
+        bv[e] = (d.bias != nullptr && n < d.N) ? d.bias[n] : 0.f;
+    }
+    for (int r = rl; r < bm; r += RPP) {
+        const int m = m0 + r;
+        int op = -1;
+        if (m < M) {
+            if (flat) {
+                op = m;
+            } else {
+                const int b = m / GHW;
+                const int rem = m - b * GHW;
+                const int gy = rem / d.GW;
+                const int gx = rem - gy * d.GW;
+                const int oy = gy * d.OSY + d.ooy[phase];
+                const int ox = gx * d.OSX + d.oox[phase];
+                if (oy < d.OH && ox < d.OW) op = (b * d.OH + oy) * d.OW + ox;
+            }
+        }
+        if (op < 0 || n0 + cv >= d.OC) continue;
+        float v[VE];
+#pragma unroll
+        for (int e = 0; e < VE; ++e) v[e] = 0.f;
+        if (n0 + cv < Npad) {
+            const float* src = base + (int64_t)m * Npad + n0 + cv;
+            for (int k = 0; k < ksplit; ++k) {                // fixed order k = 0, 1, 2, ...
+#pragma unroll
+                for (int q4 = 0; q4 < VE / 4; ++q4) {
+                    const float4 t = *reinterpret_cast<const float4*>(src + (int64_t)k * kstride + 4 * q4);
+                    v[4 * q4] += t.x; v[4 * q4 + 1] += t.y; v[4 * q4 + 2] += t.z; v[4 * q4 + 3] += t.w;
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+            const bool real = n0 + cv + e < d.N;
+            v[e] = real ? v[e] + bv[e] : 0.f;
+            s1[e] += v[e];
+            s2[e] += v[e] * v[e];
+        }
+        if constexpr (DT == VG_F32) {
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(d.Y) + (int64_t)op * d.OC + n0 + cv) = float4{v[0], v[1], v[2], v[3]};
+        } else {
+            u32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                o[k] = (uint32_t)ElemT<VG_BF16>::from_f32(v[2 * k]) | ((uint32_t)ElemT<VG_BF16>::from_f32(v[2 * k + 1]) << 16);
+            *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(d.Y) + (int64_t)op * d.OC + n0 + cv) = o;
+        }
+    }
+    if (d.stats == nullptr) return;
+#pragma unroll
+    for (int e = 0; e < VE; ++e) { red[0][rl][cv + e] = s1[e]; red[1][rl][cv + e] = s2[e]; }
+    __syncthreads();
+    if (tid < 128) {
+        const int which = tid >> 6, c = tid & 63;
+        float a = 0.f;
+        for (int t = 0; t < RPP; ++t) a += red[which][t][c];
+        if (n0 + c < d.N) {
+            const int m_tiles = (M + bm - 1) / bm;
+            d.stats[(((int64_t)phase * m_tiles + blockIdx.x) * 2 + which) * d.N + n0 + c] = a;
+        }
+    }
+}
+
 #include "conv_patch.hpp"
 #include "conv_phase4.hpp"
 #include "conv_narrowk.hpp"
@@ -768,31 +857,45 @@ inline int validate(const vg_gg_desc* d, int dtype) {
     return 0;
 }
 
-// Split K only for skinny problems: one phase, flat output, no BN statistics, <= 32 output tiles, >= 16 stages.
+// Split K for skinny problems -- few output tiles, long K.  Round 4: also with sub-pixel phases and with BatchNorm statistics
+// (formed by the slab reduce, splitk_reduce2_kernel), on the LDS-DMA ring; never with a fused activation or mask (their
+// epilogues need final values).  `dma`: the split launch will run on the DMA kernel (stage = DmaRing<bm, bn>::KCH chunks).
+inline bool split_dma_ok(const vg_gg_desc* d, int dtype, TileCfg t) {
+    return dtype == VG_BF16 && (t.bn % 64) == 0 && (t.bm == 64 || t.bm == 128) && use_dma() && d->zeros != nullptr;
+}
 inline SplitK plan_splitk(const vg_gg_desc* d, int dtype, TileCfg t) {
     SplitK r{1, 0, 0};
     const int M = d->B * d->GH * d->GW;
     const bool flat = d->nphase == 1 && d->OSY == 1 && d->OSX == 1 && d->GH == d->OH && d->GW == d->OW;
-    if (!flat || d->stats != nullptr || d->act != VG_ACT_NONE || d->mask_x != nullptr || dtype == VG_FP8) return r;
-    if (t.bm == 256 && t.bn >= 32) return r;                    // the 256-row tiles exist as patch / 4-phase kernels only: no split form
+    const bool general = vg_sw().splitk_general != 0 && dtype == VG_BF16;     // phases / statistics allowed
+    if (d->act != VG_ACT_NONE || d->mask_x != nullptr || dtype == VG_FP8) return r;
+    if ((!flat || d->stats != nullptr) && !general) return r;
+    if (t.bm == 256 || t.bn < 64) return r;                     // 256-row / narrow tiles: patch, 4-phase and edge kernels only
     const int esz = dtype == VG_F32 ? 4 : 2;
-    const int kch = dtype == VG_BF16 ? 2 : 1;
+    const bool dma = split_dma_ok(d, dtype, t);
+    int kch = dtype == VG_BF16 ? 2 : 1;
+    if (dma) kch = t.bm == 128 ? (t.bn == 128 ? 2 : VG_RING128x64_KCH) : VG_RING64_KCH;
     const int nstages = ((d->Kp * esz) / 64 + kch - 1) / kch;
     const int gx = (M + t.bm - 1) / t.bm, gy = (d->N + t.bn - 1) / t.bn;
-    const int tiles = gx * gy;
+    const int tiles = gx * gy * d->nphase;
     const int max_tiles = vg_sw().splitk_max_tiles;
     const bool bigk = t.bm == 128 && t.bn == 128 && bigk_split_ok(d, dtype == VG_BF16);
-    if ((tiles > max_tiles && !bigk) || nstages < 16) return r;
+    // the round-4 cases: 64 x 64-tile launches (the small-M layers) of up to one workgroup per CU unsplit; the 128-row tiles keep
+    // their patch kernels (faster than the generic tile a split launch would run on)
+    const bool wide = general && (!flat || d->stats != nullptr);
+    if (wide && t.bm != 64) return r;
+    if ((tiles > (wide ? 256 : max_tiles) && !bigk) || nstages < (dma && t.bm == 64 ? 8 : 16)) return r;
     // aim at ~4 workgroups per CU, at most 64 splits (the Encoder's Linear layers -- 4 tiles, K = 50 176 at S = 256 -- are at
-    // their best there; more splits only add partial traffic), at least 4 stages per split.  The big-K case aims at 2
-    // workgroups per CU: its f32 partials are the price (128 tiles x 64 KB per slice)
+    // their best there; more splits only add partial traffic), at least 4 stages per split (2 of the 4-chunk stages of the
+    // 64 x 64 DMA tile).  The big-K case aims at 2 workgroups per CU: its f32 partials are the price (128 tiles x 64 KB per slice)
     int ks = (bigk ? 512 : vg_sw().splitk_wgs) / tiles;
     if (ks > 64) ks = 64;
-    if (ks > nstages / 4) ks = nstages / 4;
+    const int min_sps = (dma && t.bm == 64) ? 2 : 4;
+    if (ks > nstages / min_sps) ks = nstages / min_sps;
     if (ks < 2) return r;
     r.sps = (nstages + ks - 1) / ks;
     r.ksplit = (nstages + r.sps - 1) / r.sps;
-    r.ws_bytes = (int64_t)r.ksplit * gx * t.bm * (int64_t)(gy * t.bn) * 4;
+    r.ws_bytes = (int64_t)d->nphase * r.ksplit * gx * t.bm * (int64_t)(gy * t.bn) * 4;
     return r;
 }
 
@@ -813,7 +916,7 @@ int launch(const vg_gg_desc* d, hipStream_t s, SplitK sk) {
     const int M = d->B * d->GH * d->GW;
     const bool split = sk.ksplit > 1 && d->ws != nullptr && d->ws_bytes >= sk.ws_bytes;
     const int m_tiles = (M + BM - 1) / BM, n_tiles = (d->N + BN - 1) / BN;
-    dim3 grid(((m_tiles + 7) / 8) * 8 * n_tiles, 1, split ? sk.ksplit : d->nphase);
+    dim3 grid(((m_tiles + 7) / 8) * 8 * n_tiles, 1, d->nphase);
     const int nstages_all = 1 << 30;
     const int one = 1 | (n_major(d, n_tiles, ElemT<DT>::size) ? GG_N_MAJOR : 0);
     constexpr bool CAN_DMA = (DT == VG_BF16 || DT == VG_FP8) && (BN % 64 == 0);
@@ -824,9 +927,10 @@ int launch(const vg_gg_desc* d, hipStream_t s, SplitK sk) {
         else vg_launch_timed(3, gg_kernel<DT, BM, BN, WM, WN, false, false>, grid, dim3(256), 0, s, *d, one, nstages_all);
         return VG_LAUNCH_RC();
     } else if (split) {
+        grid.z = d->nphase * sk.ksplit;
         bool launched = false;
-        if constexpr (CAN_DMA && BM >= 128) {                  // round 4: K slices on the LDS-DMA ring too (128-row tiles)
-            if (dma) {
+        if constexpr (CAN_DMA && (BM == 64 || BM == 128)) {     // round 4: K slices on the LDS-DMA ring too
+            if (dma && split_dma_ok(d, DT, TileCfg{BM, BN})) {
                 vg_launch_timed(0, gg_kernel<DT, BM, BN, WM, WN, true, true>, grid, dim3(256), 0, s, *d, sk.ksplit, sk.sps);
                 launched = true;
             }
@@ -841,12 +945,20 @@ int launch(const vg_gg_desc* d, hipStream_t s, SplitK sk) {
     }
     int rc = VG_LAUNCH_RC();
     if (rc || !split) return rc;
-    const int64_t total = (int64_t)M * d->OC;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    if constexpr (DT != VG_FP8)
-        hipLaunchKernelGGL(splitk_reduce_kernel<DT>, dim3(blocks), dim3(256), 0, s, d->ws, sk.ksplit, M, d->N, d->OC,
-                           m_tiles * BM, n_tiles * BN, d->bias, d->Y);
+    if constexpr (DT != VG_FP8) {
+        const bool flat = d->nphase == 1 && d->OSY == 1 && d->OSX == 1 && d->GH == d->OH && d->GW == d->OW;
+        if (flat && d->stats == nullptr) {                    // the round-1 reduce: elementwise over the flat output
+            const int64_t total = (int64_t)M * d->OC;
+            int blocks = (int)((total + 255) / 256);
+            if (blocks > 2048) blocks = 2048;
+            hipLaunchKernelGGL(splitk_reduce_kernel<DT>, dim3(blocks), dim3(256), 0, s, d->ws, sk.ksplit, M, d->N, d->OC,
+                               m_tiles * BM, n_tiles * BN, d->bias, d->Y);
+        } else {
+            // (the output's padding channels [N, OC) of a pixel are written as zeros by the 64-column blocks that cover them)
+            hipLaunchKernelGGL(splitk_reduce2_kernel<DT>, dim3(m_tiles, (d->OC + 63) / 64, d->nphase), dim3(256), 0, s, *d,
+                               sk.ksplit, BM, m_tiles * BM, n_tiles * BN);
+        }
+    }
     return VG_LAUNCH_RC();
 }
 

@@ -997,6 +997,7 @@ void read_switches() {
     g_sw.splitk_max_tiles = env_int("VG_SPLITK_MAX_TILES", 128);
     g_sw.splitk_wgs = env_int("VG_SPLITK_WGS", 1024);
     g_sw.splitk_bigk = env_int("VG_SPLITK_BIGK", 1);
+    g_sw.splitk_general = env_int("VG_SPLITK_GENERAL", 0);
     g_sw.gg_nmajor = env_int("VG_GG_NMAJOR", 1);
     g_sw.edge = env_int("VG_EDGE", 1);
     g_sw.wg_reduce_t = env_int("VG_WG_REDUCE_T", 1);
