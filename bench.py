@@ -382,10 +382,12 @@ def main():
     if multi:
         dist.barrier()
     torch.cuda.synchronize()
+    n_launch_timed = ops.launch_count()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         losses = step_fn(real, epoch, ez, er, ec)
     torch.cuda.synchronize()
+    n_launch_timed = ops.launch_count() - n_launch_timed
     if multi:
         dist.barrier()
     torch.cuda.synchronize()
@@ -409,7 +411,7 @@ def main():
         ops.set_timer(None)
         launches_per_step = (ops.launch_count() - n_launch0) / args.steps
     else:
-        launches_per_step = None
+        launches_per_step = n_launch_timed / args.steps      # eager launches: the timed region itself
     if rank != 0:
         if multi:
             dist.destroy_process_group()
