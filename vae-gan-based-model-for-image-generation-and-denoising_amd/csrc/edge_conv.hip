@@ -28,6 +28,16 @@ __device__ __forceinline__ int fdiv(int a, int b, float inv) {
     return q;
 }
 
+// component j of the Normal4 held by lane SRC of this lane's quad (quad-broadcast DPP moves: quad_perm [SRC, SRC, SRC, SRC])
+template <int SRC>
+__device__ __forceinline__ float quad_pick(const Normal4& blk, int j) {
+    float c[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        c[k] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(blk.v[k]), SRC * 0x55, 0xf, 0xf, false));
+    return j == 0 ? c[0] : j == 1 ? c[1] : j == 2 ? c[2] : c[3];
+}
+
 // NT 16-column tiles of j (K*K*N <= 16*NT), KC 32-channel chunks (C = 32*KC), NPIX input pixels (halo rows included)
 // per workgroup, K x K taps at stride S (compile time: the col2im loop unrolls to its 9 | 4 live taps, no divisions)
 template <int NT, int KC, int NPIX, int K, int S>
@@ -118,6 +128,10 @@ __global__ __launch_bounds__(256) void tnconv_kernel(const vg_tn_desc d, const i
     const int ix_end = min(d.IW, c0 + TC);                    // input columns [c0, ix_end) are in the window
     const NoiseSrc nz{d.eps, reinterpret_cast<const unsigned long long*>(d.rng), (uint32_t)d.draw};
     const bool noisy = d.eps != nullptr || d.rng != nullptr;
+    // quads of lanes = four consecutive pixels of one row whose NCHW indices start at a multiple of 4 (every channel plane
+    // and row is a multiple of 4 long, the tile's columns start and end on multiples of 4: count % 4 == 0 too, so a quad
+    // is complete in every pass)
+    const bool quad_noise = d.eps == nullptr && d.rng != nullptr && (cw & 3) == 0 && (ox_a & 3) == 0 && (d.OW & 3) == 0;
     unsigned char* Yb = reinterpret_cast<unsigned char*>(d.Y);
     const int N = d.N;
     for (int q = tid; q < count; q += 256) {
@@ -143,6 +157,23 @@ __global__ __launch_bounds__(256) void tnconv_kernel(const vg_tn_desc d, const i
         }
         const int64_t opix = ((int64_t)b * d.OH + oy) * d.OW + ox;
         float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        // In-kernel noise, shared by lane quads (round 4): the four lanes of a quad hold four consecutive pixels of one
+        // output row, i.e. for each channel the four elements of ONE Philox block (element idx = component idx & 3 of
+        // block idx >> 2).  Lane j < N of the quad generates channel j's block (four normals), quad-broadcast DPP moves hand
+        // every lane its component: one Philox + two Box-Muller pairs per lane instead of N of each -- the same values.
+        float nzv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (quad_noise) {
+            const int j = lane & 3;
+            const int jn = j < N ? j : 0;
+            const int64_t cj = (((int64_t)b * N + jn) * d.OH + oy) * d.OW + (ox - j);      // first pixel of the quad, channel jn
+            const Normal4 blk = philox_randn4(nz.rng[0], nz.rng[1], nz.draw, (unsigned long long)cj >> 2);
+            // what lane j needs of channel n's block is component j: select it on the SOURCE side (every lane picks its
+            // own v[j] ... no: the source lane n must supply v[j of the destination]) -> broadcast all four, pick locally
+            nzv[0] = quad_pick<0>(blk, j);
+            if (N > 1) nzv[1] = quad_pick<1>(blk, j);
+            if (N > 2) nzv[2] = quad_pick<2>(blk, j);
+            if (N > 3) nzv[3] = quad_pick<3>(blk, j);
+        }
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             if (n < N) {
@@ -150,7 +181,8 @@ __global__ __launch_bounds__(256) void tnconv_kernel(const vg_tn_desc d, const i
                 if (d.act == VG_ACT_TANH) t = tanhf(t);
                 const int64_t cidx = (((int64_t)b * N + n) * d.OH + oy) * d.OW + ox;      // NCHW index (noise order too)
                 if (d.Y_nchw) d.Y_nchw[cidx] = t;
-                if (noisy) t = t + d.sigma * noise_at(nz, cidx);
+                if (quad_noise) t = t + d.sigma * nzv[n];
+                else if (noisy) t = t + d.sigma * noise_at(nz, cidx);
                 o[n] = t;
             }
         }
@@ -200,8 +232,10 @@ inline int tn_plan(const vg_tn_desc* d, TnPlan* p) {
         return RO;
     };
     auto co_for = [&](int tc) {                     // largest block of output columns (a multiple of S) behind tc input columns
+        // (with in-kernel noise: a multiple of 4, so that lane quads own whole Philox blocks -- quad_noise in the kernel)
+        const int cstep = (d->rng != nullptr && d->OW % 4 == 0) ? 4 : d->S;
         int CO = 0;
-        for (int c = d->S; c <= d->OW + d->S; c += d->S) {
+        for (int c = cstep; c <= d->OW + cstep; c += cstep) {
             const int need = (c - 1 + d->K - 1) / d->S + 1;
             if (need > tc) break;
             CO = c;
@@ -259,6 +293,11 @@ inline void tn_launch(const vg_tn_desc* d, const TnPlan& p, hipStream_t s) {
 //     tiles; one [J][C] f32 partial per workgroup, summed in fixed order by edge_wgrad_reduce_kernel, which also
 //     scatters into the reference layout dW[c*s_c + n*s_n + kh*K + kw].
 constexpr int EW_TP = 256;                 // wide pixels per tile
+// bytes of LDS for the narrow patch: 22 KB beside the 32 KB wide tile of 64-channel operands (two workgroups per CU); the
+// 16- / 32-channel operands (S >= 128 members of the size family) have 8 / 16 KB wide tiles and room for a 26 KB patch -- at
+// 256-pixel-wide images that is TWO wide rows per tile instead of one (a 6 x 258-pixel patch), i.e. half the tiles and half
+// the re-read halo rows (round 4)
+constexpr int ew_patch_max(int ct) { return ct == 4 ? 22 * 1024 : 26 * 1024; }
 
 typedef __attribute__((ext_vector_type(4))) __bf16 ew_bf16x4;
 
@@ -266,7 +305,7 @@ template <int CT>                          // C = 16 * CT channels of the wide o
 __global__ __launch_bounds__(256) void edge_wgrad_kernel(const vg_ew_desc d, const int R, const int tiles_per_img,
                                                          const int ntiles, const int JT) {
     constexpr int RB = CT * 32;                                   // bytes per wide pixel
-    constexpr int PATCH_MAX = 22 * 1024;
+    constexpr int PATCH_MAX = ew_patch_max(CT);
     // [wide tile 256 x RB][patch: slot 0 = zero pixel, then PR x PW pixels of 16 B][pixel table 256 x int]
     __shared__ __attribute__((aligned(16))) unsigned char smem[EW_TP * RB + PATCH_MAX + EW_TP * 4];
     unsigned char* const wide = smem;
@@ -417,8 +456,9 @@ inline int ew_plan(const vg_ew_desc* d, EwPlan* p) {
     p->JT = (d->K * d->K * 4 + 15) / 16;                           // 3 (k3) | 4 (k4)
     p->CT = d->C / 16;
     int R = EW_TP / d->WW;
-    while (R > 1 && (int64_t)(((R - 1) * d->S + d->K) * ((d->WW - 1) * d->S + d->K) + 1) * 16 > 22 * 1024) --R;
-    VG_CHECK_ARG((int64_t)(((R - 1) * d->S + d->K) * ((d->WW - 1) * d->S + d->K) + 1) * 16 <= 22 * 1024, VG_ENOSUP);
+    const int64_t pmax = ew_patch_max(p->CT);
+    while (R > 1 && (int64_t)(((R - 1) * d->S + d->K) * ((d->WW - 1) * d->S + d->K) + 1) * 16 > pmax) --R;
+    VG_CHECK_ARG((int64_t)(((R - 1) * d->S + d->K) * ((d->WW - 1) * d->S + d->K) + 1) * 16 <= pmax, VG_ENOSUP);
     if (R > d->WH) R = d->WH;
     p->R = R;
     p->tiles_per_img = (d->WH + R - 1) / R;
